@@ -1,0 +1,103 @@
+"""ctypes binding of ``libeioku_hip.so`` (the C ABI declared in ``include/eioku_hip.h``).
+
+The product path has no CPU fallback: if the shared library is missing, or a GPU call is made
+without a gfx950 device, this module raises - it never routes around the HIP kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from pathlib import Path
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / "libeioku_hip.so"
+
+MEM_HOST = 0
+MEM_DEVICE = 1
+
+
+class EiokuHipError(RuntimeError):
+    """A libeioku_hip call returned a non-zero code (message from ``eioku_last_error``)."""
+
+
+_c_u8p = C.c_void_p  # all data pointers travel as integers (host ndarray / torch data_ptr)
+
+# name -> (restype, argtypes).  Kept in one table so tests can compare it with the header.
+SIGNATURES = {
+    "eioku_abi_version": (C.c_int, []),
+    "eioku_init": (C.c_int, [C.c_int]),
+    "eioku_shutdown": (None, []),
+    "eioku_last_error": (C.c_char_p, []),
+    "eioku_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "eioku_synth_u64": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "eioku_synth_bytes": (C.c_int, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "eioku_synth_normal_f32": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "eioku_synth_frames_bgr": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "eioku_scene_sad_luma": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "eioku_scene_hsv_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p]),
+    "eioku_bgr2hsv": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_initialised_device: int | None = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library and attach prototypes (no GPU needed for this step)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            raise EiokuHipError(
+                f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C eioku_amd/csrc`; there is no CPU fallback for the hot path")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.eioku_abi_version() != 1:
+            raise EiokuHipError(f"ABI version mismatch: library reports {lib.eioku_abi_version()}")
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return (load().eioku_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise EiokuHipError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def init(device_id: int | None = None) -> int:
+    """Select the worker's HIP device (``EIOKU_HIP_DEVICE`` / ``LOCAL_RANK`` / 0)."""
+    global _initialised_device
+    lib = load()
+    if device_id is None:
+        device_id = int(os.environ.get("EIOKU_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if _initialised_device == device_id:
+        return device_id
+    check(lib.eioku_init(device_id), f"eioku_init({device_id})")
+    _initialised_device = device_id
+    return device_id
+
+
+def device_info() -> dict:
+    lib = load()
+    init()
+    name = C.create_string_buffer(256)
+    cus = C.c_int(0)
+    hbm = C.c_uint64(0)
+    check(lib.eioku_device_info(name, 256, C.byref(cus), C.byref(hbm)), "eioku_device_info")
+    return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}

@@ -1,0 +1,72 @@
+// Shared host-side plumbing for libeioku_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/eioku_hip.h"
+
+namespace eioku {
+
+void set_error(const char* fmt, ...);
+bool initialised();
+int num_cus();
+
+// Scratch device buffer owned by the library, grown on demand (EIOKU_MEM_HOST staging and
+// per-call workspaces).  Slot ids keep independent users from aliasing each other.
+enum ScratchSlot { kSlotIn = 0, kSlotPrev, kSlotOut, kSlotWork0, kSlotWork1, kSlotWork2, kNumSlots };
+void* scratch(ScratchSlot slot, size_t bytes);  // nullptr + error set on failure
+
+}  // namespace eioku
+
+#define EIOKU_HIP_CHECK(expr)                                                                  \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      ::eioku::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,      \
+                         __LINE__);                                                            \
+      return EIOKU_EHIP;                                                                       \
+    }                                                                                          \
+  } while (0)
+
+#define EIOKU_REQUIRE(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::eioku::set_error(__VA_ARGS__);    \
+      return EIOKU_EINVAL;                \
+    }                                     \
+  } while (0)
+
+#define EIOKU_REQUIRE_INIT()                                                \
+  do {                                                                      \
+    if (!::eioku::initialised()) {                                          \
+      ::eioku::set_error("eioku_init() has not been called");               \
+      return EIOKU_ENODEV;                                                  \
+    }                                                                       \
+  } while (0)
+
+// Launch-error check that does not synchronise.
+#define EIOKU_LAUNCH_CHECK() EIOKU_HIP_CHECK(hipGetLastError())
+
+namespace eioku {
+
+__device__ __forceinline__ unsigned long long splitmix64_at(unsigned long long seed,
+                                                            unsigned long long i) {
+  unsigned long long z = seed + (i + 1ull) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_add(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+}  // namespace eioku

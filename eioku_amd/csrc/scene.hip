@@ -1,0 +1,534 @@
+// Scene scoring kernels - HBM-bound byte/integer work.
+//
+// Both kernels keep the previous frame's tile in registers while a workgroup walks a run of
+// consecutive frames, so every frame byte is read from HBM once (plus one extra frame per run
+// of `seg` frames).  Per-frame sums are exact integers: wave shuffle-reduce -> LDS -> one
+// 64-bit integer atomic per (workgroup, frame, channel); integer addition is associative, so
+// the result does not depend on scheduling.
+//
+//   K1 k_sad_luma  : sum |Y_t - Y_{t-1}|            algorithmic bytes = W*H   per frame
+//   K2 k_hsv_sums  : OpenCV 8-bit BGR->HSV, then sum |c_t - c_{t-1}| for c in {H,S,V}
+//                                                   algorithmic bytes = 3*W*H per frame
+#include "common.h"
+
+#include <cmath>
+
+using namespace eioku;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kG = 8;  // frames whose partial sums live in registers between reductions
+
+// OpenCV RGB2HSV_b tables (hsv_shift = 12, hrange = 180), filled once on the host with
+// cvRound == lrint semantics, then copied to constant memory.
+__constant__ int c_sdiv[256];
+__constant__ int c_hdiv[256];
+bool g_tables_ready = false;
+
+int ensure_tables() {
+  if (g_tables_ready) return EIOKU_OK;
+  int sdiv[256], hdiv[256];
+  sdiv[0] = hdiv[0] = 0;
+  for (int i = 1; i < 256; ++i) {
+    sdiv[i] = (int)lrint((255 << 12) / (1.0 * i));
+    hdiv[i] = (int)lrint((180 << 12) / (6.0 * i));
+  }
+  EIOKU_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_sdiv), sdiv, sizeof(sdiv)));
+  EIOKU_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_hdiv), hdiv, sizeof(hdiv)));
+  g_tables_ready = true;
+  return EIOKU_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// shared reduction tail: acc[G][C] per thread -> atomics on out[(t0+k)*C + c]
+// ---------------------------------------------------------------------------------------
+template <int G, int C>
+__device__ __forceinline__ void flush_sums(unsigned (&acc)[G][C], unsigned (*s_red)[G * C], int t0,
+                                           int t_end, unsigned long long* out) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < G; ++k)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      unsigned v = wave_reduce_add(acc[k][c]);
+      if (lane == 0) s_red[wave][k * C + c] = v;
+    }
+  __syncthreads();
+  if (tid < G * C) {
+    int k = tid / C;
+    if (t0 + k < t_end) {
+      unsigned long long v = 0;
+#pragma unroll
+      for (int wv = 0; wv < kBlock / 64; ++wv) v += s_red[wv][tid];
+      if (v) atomicAdd(&out[(size_t)(t0 + k) * C + (tid % C)], v);
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+// K1: luma SAD.  Contiguous planes: thread owns U x 16 B of the plane.
+// ---------------------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(kBlock) void k_sad_luma(const uint8_t* __restrict__ frames,
+                                                     size_t frame_stride, int n,
+                                                     unsigned long long plane_bytes,
+                                                     const uint8_t* __restrict__ prev, int seg,
+                                                     unsigned long long* __restrict__ sad) {
+  __shared__ unsigned s_red[kBlock / 64][kG];
+  const int tid = threadIdx.x;
+  const unsigned long long nvec = plane_bytes >> 4;  // the <16-byte tail goes to k_sad_luma_strided
+  const int t_begin = blockIdx.y * seg;
+  const int t_end = min(n, t_begin + seg);
+
+  unsigned long long vidx[U];
+  bool live[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    vidx[u] = ((unsigned long long)blockIdx.x * U + u) * kBlock + tid;
+    live[u] = vidx[u] < nvec;
+  }
+
+  uint4 p[U];
+  const uint8_t* pf = t_begin > 0 ? frames + (size_t)(t_begin - 1) * frame_stride : prev;
+  bool have_prev = pf != nullptr;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    p[u] = make_uint4(0, 0, 0, 0);
+    if (have_prev && live[u]) p[u] = reinterpret_cast<const uint4*>(pf)[vidx[u]];
+  }
+
+  for (int t0 = t_begin; t0 < t_end; t0 += kG) {
+    unsigned acc[kG][1];
+#pragma unroll
+    for (int k = 0; k < kG; ++k) acc[k][0] = 0;
+#pragma unroll
+    for (int k = 0; k < kG; ++k) {
+      const int t = t0 + k;
+      if (t < t_end) {
+        const uint8_t* f = frames + (size_t)t * frame_stride;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          uint4 c = make_uint4(0, 0, 0, 0);
+          if (live[u]) c = reinterpret_cast<const uint4*>(f)[vidx[u]];
+          if (have_prev) {
+            unsigned a = acc[k][0];
+            a = __builtin_amdgcn_sad_u8(c.x, p[u].x, a);
+            a = __builtin_amdgcn_sad_u8(c.y, p[u].y, a);
+            a = __builtin_amdgcn_sad_u8(c.z, p[u].z, a);
+            a = __builtin_amdgcn_sad_u8(c.w, p[u].w, a);
+            acc[k][0] = a;
+          }
+          p[u] = c;
+        }
+        have_prev = true;
+      }
+    }
+    flush_sums<kG, 1>(acc, s_red, t0, t_end, sad);
+  }
+}
+
+// Generic (row-strided or unaligned) planes: byte loads, 16 pixels per thread.
+__global__ __launch_bounds__(kBlock) void k_sad_luma_strided(const uint8_t* __restrict__ frames,
+                                                             size_t frame_stride,
+                                                             size_t row_stride, int n, int h, int w,
+                                                             unsigned long long pix_begin,
+                                                             const uint8_t* __restrict__ prev,
+                                                             int seg,
+                                                             unsigned long long* __restrict__ sad) {
+  __shared__ unsigned s_red[kBlock / 64][kG];
+  const int tid = threadIdx.x;
+  const unsigned long long npix = (unsigned long long)h * w;
+  const unsigned long long i0 = pix_begin + ((unsigned long long)blockIdx.x * kBlock + tid) * 16;
+  const int t_begin = blockIdx.y * seg;
+  const int t_end = min(n, t_begin + seg);
+  size_t off[16];
+  bool live[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    unsigned long long i = i0 + j;
+    live[j] = i < npix;
+    unsigned long long y = live[j] ? i / w : 0;
+    off[j] = live[j] ? y * row_stride + (i - y * w) : 0;
+  }
+  uint8_t p[16];
+  const uint8_t* pf = t_begin > 0 ? frames + (size_t)(t_begin - 1) * frame_stride : prev;
+  bool have_prev = pf != nullptr;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) p[j] = (have_prev && live[j]) ? pf[off[j]] : 0;
+  for (int t0 = t_begin; t0 < t_end; t0 += kG) {
+    unsigned acc[kG][1];
+#pragma unroll
+    for (int k = 0; k < kG; ++k) acc[k][0] = 0;
+#pragma unroll
+    for (int k = 0; k < kG; ++k) {
+      const int t = t0 + k;
+      if (t < t_end) {
+        const uint8_t* f = frames + (size_t)t * frame_stride;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          uint8_t c = live[j] ? f[off[j]] : 0;
+          if (have_prev) acc[k][0] += (unsigned)abs((int)c - (int)p[j]);
+          p[j] = c;
+        }
+        have_prev = true;
+      }
+    }
+    flush_sums<kG, 1>(acc, s_red, t0, t_end, sad);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: BGR -> HSV (OpenCV RGB2HSV_b, hrange 180) + per-channel SAD against the previous frame
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void hsv_px(int b, int g, int r, const int* __restrict__ sdiv,
+                                       const int* __restrict__ hdiv, int& H, int& S, int& V) {
+  int v = max(max(b, g), r);
+  int vmin = min(min(b, g), r);
+  int diff = v - vmin;
+  int s = (__mul24(diff, sdiv[v]) + 2048) >> 12;
+  int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+  h = (__mul24(h, hdiv[diff]) + 2048) >> 12;  // arithmetic shift: floor, as in the C source
+  h += (h < 0) ? 180 : 0;
+  H = h;
+  S = s;
+  V = v;
+}
+
+// 4 pixels = 12 bytes = 3 dwords -> packed H, S, V quads (one byte per pixel)
+__device__ __forceinline__ void hsv_quad(unsigned d0, unsigned d1, unsigned d2,
+                                         const int* __restrict__ sdiv,
+                                         const int* __restrict__ hdiv, unsigned& H, unsigned& S,
+                                         unsigned& V) {
+  int h0, s0, v0, h1, s1, v1, h2, s2, v2, h3, s3, v3;
+  hsv_px(d0 & 0xFF, (d0 >> 8) & 0xFF, (d0 >> 16) & 0xFF, sdiv, hdiv, h0, s0, v0);
+  hsv_px(d0 >> 24, d1 & 0xFF, (d1 >> 8) & 0xFF, sdiv, hdiv, h1, s1, v1);
+  hsv_px((d1 >> 16) & 0xFF, d1 >> 24, d2 & 0xFF, sdiv, hdiv, h2, s2, v2);
+  hsv_px((d2 >> 8) & 0xFF, (d2 >> 16) & 0xFF, d2 >> 24, sdiv, hdiv, h3, s3, v3);
+  H = (unsigned)h0 | ((unsigned)h1 << 8) | ((unsigned)h2 << 16) | ((unsigned)h3 << 24);
+  S = (unsigned)s0 | ((unsigned)s1 << 8) | ((unsigned)s2 << 16) | ((unsigned)s3 << 24);
+  V = (unsigned)v0 | ((unsigned)v1 << 8) | ((unsigned)v2 << 16) | ((unsigned)v3 << 24);
+}
+
+struct Quad3 {
+  unsigned d0, d1, d2;
+};
+
+template <bool ALIGNED>
+__device__ __forceinline__ Quad3 load_quad(const uint8_t* __restrict__ f, unsigned long long q) {
+  Quad3 r;
+  if (ALIGNED) {
+    const unsigned* p = reinterpret_cast<const unsigned*>(f) + q * 3;
+    r.d0 = p[0];
+    r.d1 = p[1];
+    r.d2 = p[2];
+  } else {
+    const uint8_t* p = f + q * 12;
+    r.d0 = p[0] | (p[1] << 8) | (p[2] << 16) | ((unsigned)p[3] << 24);
+    r.d1 = p[4] | (p[5] << 8) | (p[6] << 16) | ((unsigned)p[7] << 24);
+    r.d2 = p[8] | (p[9] << 8) | (p[10] << 16) | ((unsigned)p[11] << 24);
+  }
+  return r;
+}
+
+// thread owns Q pixel quads per frame; a workgroup covers Q*256 quads = Q*1024 pixels.
+template <int Q, bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void k_hsv_sums(const uint8_t* __restrict__ frames,
+                                                     size_t frame_stride, int n,
+                                                     unsigned long long npix,
+                                                     const uint8_t* __restrict__ prev, int seg,
+                                                     unsigned long long* __restrict__ sums) {
+  __shared__ int s_sdiv[256];
+  __shared__ int s_hdiv[256];
+  __shared__ unsigned s_red[kBlock / 64][kG * 3];
+  const int tid = threadIdx.x;
+  s_sdiv[tid] = c_sdiv[tid];
+  s_hdiv[tid] = c_hdiv[tid];
+  __syncthreads();
+
+  const unsigned long long nquads = npix >> 2;  // the <4-pixel tail goes to k_hsv_sums_tail
+  const int t_begin = blockIdx.y * seg;
+  const int t_end = min(n, t_begin + seg);
+
+  unsigned long long q[Q];
+  bool live[Q];
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    q[u] = ((unsigned long long)blockIdx.x * Q + u) * kBlock + tid;
+    live[u] = q[u] < nquads;
+  }
+
+  unsigned pH[Q], pS[Q], pV[Q];
+  const uint8_t* pf = t_begin > 0 ? frames + (size_t)(t_begin - 1) * frame_stride : prev;
+  bool have_prev = pf != nullptr;
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    pH[u] = pS[u] = pV[u] = 0;
+    if (have_prev && live[u]) {
+      Quad3 d = load_quad<ALIGNED>(pf, q[u]);
+      hsv_quad(d.d0, d.d1, d.d2, s_sdiv, s_hdiv, pH[u], pS[u], pV[u]);
+    }
+  }
+
+  for (int t0 = t_begin; t0 < t_end; t0 += kG) {
+    unsigned acc[kG][3];
+#pragma unroll
+    for (int k = 0; k < kG; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0;
+#pragma unroll
+    for (int k = 0; k < kG; ++k) {
+      const int t = t0 + k;
+      if (t < t_end) {
+        const uint8_t* f = frames + (size_t)t * frame_stride;
+        Quad3 d[Q];
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+          d[u].d0 = d[u].d1 = d[u].d2 = 0;
+          if (live[u]) d[u] = load_quad<ALIGNED>(f, q[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+          unsigned H = 0, S = 0, V = 0;
+          if (live[u]) hsv_quad(d[u].d0, d[u].d1, d[u].d2, s_sdiv, s_hdiv, H, S, V);
+          if (have_prev) {
+            acc[k][0] = __builtin_amdgcn_sad_u8(H, pH[u], acc[k][0]);
+            acc[k][1] = __builtin_amdgcn_sad_u8(S, pS[u], acc[k][1]);
+            acc[k][2] = __builtin_amdgcn_sad_u8(V, pV[u], acc[k][2]);
+          }
+          pH[u] = H;
+          pS[u] = S;
+          pV[u] = V;
+        }
+        have_prev = true;
+      }
+    }
+    flush_sums<kG, 3>(acc, s_red, t0, t_end, sums);
+  }
+}
+
+// pixels [pix_begin, npix) (< 4 of them): one thread per pixel walks all frames.
+__global__ void k_hsv_sums_tail(const uint8_t* __restrict__ frames, size_t frame_stride, int n,
+                                unsigned long long pix_begin, unsigned long long npix,
+                                const uint8_t* __restrict__ prev,
+                                unsigned long long* __restrict__ sums) {
+  __shared__ int s_sdiv[256];
+  __shared__ int s_hdiv[256];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+    s_sdiv[i] = c_sdiv[i];
+    s_hdiv[i] = c_hdiv[i];
+  }
+  __syncthreads();
+  unsigned long long i = pix_begin + threadIdx.x;
+  if (i >= npix) return;
+  int pH = 0, pS = 0, pV = 0;
+  bool have_prev = prev != nullptr;
+  if (have_prev) hsv_px(prev[i * 3], prev[i * 3 + 1], prev[i * 3 + 2], s_sdiv, s_hdiv, pH, pS, pV);
+  for (int t = 0; t < n; ++t) {
+    const uint8_t* px = frames + (size_t)t * frame_stride + i * 3;
+    int H, S, V;
+    hsv_px(px[0], px[1], px[2], s_sdiv, s_hdiv, H, S, V);
+    if (have_prev) {
+      atomicAdd(&sums[(size_t)t * 3 + 0], (unsigned long long)abs(H - pH));
+      atomicAdd(&sums[(size_t)t * 3 + 1], (unsigned long long)abs(S - pS));
+      atomicAdd(&sums[(size_t)t * 3 + 2], (unsigned long long)abs(V - pV));
+    }
+    pH = H;
+    pS = S;
+    pV = V;
+    have_prev = true;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bgr2hsv(const uint8_t* __restrict__ bgr,
+                                                    unsigned long long npix,
+                                                    uint8_t* __restrict__ out) {
+  __shared__ int s_sdiv[256];
+  __shared__ int s_hdiv[256];
+  s_sdiv[threadIdx.x] = c_sdiv[threadIdx.x];
+  s_hdiv[threadIdx.x] = c_hdiv[threadIdx.x];
+  __syncthreads();
+  unsigned long long i = blockIdx.x * (unsigned long long)kBlock + threadIdx.x;
+  unsigned long long stride = (unsigned long long)gridDim.x * kBlock;
+  for (; i < npix; i += stride) {
+    int H, S, V;
+    hsv_px(bgr[i * 3], bgr[i * 3 + 1], bgr[i * 3 + 2], s_sdiv, s_hdiv, H, S, V);
+    out[i * 3] = (uint8_t)H;
+    out[i * 3 + 1] = (uint8_t)S;
+    out[i * 3 + 2] = (uint8_t)V;
+  }
+}
+
+// Split n frames into runs of `seg` (multiple of kG) so the grid has >= ~8 workgroups per CU
+// when the frame is small, while keeping the one-extra-frame-per-run overhead low.
+int pick_seg(int n, unsigned long long blocks_x) {
+  const unsigned long long want = (unsigned long long)num_cus() * 8;
+  int seg = ((n + kG - 1) / kG) * kG;  // one run
+  while (seg > 2 * kG && blocks_x * (unsigned long long)((n + seg - 1) / seg) < want) {
+    seg = ((seg / 2 + kG - 1) / kG) * kG;
+  }
+  return seg < kG ? kG : seg;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eioku_scene_sad_luma(const uint8_t* y_frames, int n, int h, int w, size_t row_stride,
+                         size_t frame_stride, const uint8_t* prev, uint64_t* sad_out, int mem,
+                         void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape n=%d h=%d w=%d", n, h, w);
+  EIOKU_REQUIRE(mem == EIOKU_MEM_HOST || mem == EIOKU_MEM_DEVICE, "bad mem flag %d", mem);
+  EIOKU_REQUIRE(row_stride >= (size_t)w, "row_stride %zu < w %d", row_stride, w);
+  EIOKU_REQUIRE(frame_stride >= row_stride * (size_t)(h - 1) + (size_t)w || n <= 1,
+                "frame_stride %zu too small", frame_stride);
+  if (n == 0) return EIOKU_OK;
+  EIOKU_REQUIRE(y_frames && sad_out, "NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+
+  const uint8_t* d_frames = y_frames;
+  const uint8_t* d_prev = prev;
+  unsigned long long* d_out = (unsigned long long*)sad_out;
+  const size_t plane_span = row_stride * (size_t)(h - 1) + (size_t)w;
+  if (mem == EIOKU_MEM_HOST) {
+    size_t total = frame_stride * (size_t)(n - 1) + plane_span;
+    uint8_t* din = (uint8_t*)scratch(kSlotIn, total);
+    d_out = (unsigned long long*)scratch(kSlotOut, sizeof(uint64_t) * n);
+    if (!din || !d_out) return EIOKU_ENOMEM;
+    EIOKU_HIP_CHECK(hipMemcpyAsync(din, y_frames, total, hipMemcpyHostToDevice, stream));
+    d_frames = din;
+    if (prev) {
+      uint8_t* dp = (uint8_t*)scratch(kSlotPrev, plane_span);
+      if (!dp) return EIOKU_ENOMEM;
+      EIOKU_HIP_CHECK(hipMemcpyAsync(dp, prev, plane_span, hipMemcpyHostToDevice, stream));
+      d_prev = dp;
+    }
+  }
+  EIOKU_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint64_t) * n, stream));
+
+  const bool contiguous = row_stride == (size_t)w;
+  const bool aligned = (((uintptr_t)d_frames | frame_stride | (d_prev ? (uintptr_t)d_prev : 0)) & 15) == 0;
+  if (contiguous && aligned) {
+    constexpr int U = 2;
+    unsigned long long plane = (unsigned long long)h * w;
+    unsigned long long nvec = plane >> 4;
+    unsigned long long bx = (nvec + (unsigned long long)kBlock * U - 1) / ((unsigned long long)kBlock * U);
+    if (bx == 0) bx = 1;
+    int seg = pick_seg(n, bx);
+    dim3 grid((unsigned)bx, (unsigned)((n + seg - 1) / seg));
+    if (nvec)
+      hipLaunchKernelGGL(k_sad_luma<U>, grid, dim3(kBlock), 0, stream, d_frames, frame_stride, n,
+                         plane, d_prev, seg, d_out);
+    if (plane & 15)  // ragged tail (< 16 bytes)
+      hipLaunchKernelGGL(k_sad_luma_strided, dim3(1, 1), dim3(kBlock), 0, stream, d_frames,
+                         frame_stride, row_stride, n, h, w, nvec << 4, d_prev,
+                         ((n + kG - 1) / kG) * kG, d_out);
+  } else {
+    unsigned long long npix = (unsigned long long)h * w;
+    unsigned long long bx = (npix + kBlock * 16ull - 1) / (kBlock * 16ull);
+    int seg = pick_seg(n, bx);
+    dim3 grid((unsigned)bx, (unsigned)((n + seg - 1) / seg));
+    hipLaunchKernelGGL(k_sad_luma_strided, grid, dim3(kBlock), 0, stream, d_frames, frame_stride,
+                       row_stride, n, h, w, 0ull, d_prev, seg, d_out);
+  }
+  EIOKU_LAUNCH_CHECK();
+  if (mem == EIOKU_MEM_HOST) {
+    EIOKU_HIP_CHECK(hipMemcpyAsync(sad_out, d_out, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, stream));
+    EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return EIOKU_OK;
+}
+
+int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t frame_stride,
+                         const uint8_t* prev, uint64_t* sums_out, int mem, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape n=%d h=%d w=%d", n, h, w);
+  EIOKU_REQUIRE(mem == EIOKU_MEM_HOST || mem == EIOKU_MEM_DEVICE, "bad mem flag %d", mem);
+  const size_t frame_bytes = (size_t)h * w * 3;
+  EIOKU_REQUIRE(frame_stride >= frame_bytes || n <= 1, "frame_stride %zu < frame bytes %zu",
+                frame_stride, frame_bytes);
+  if (n == 0) return EIOKU_OK;
+  EIOKU_REQUIRE(bgr_frames && sums_out, "NULL pointer");
+  int rc = ensure_tables();
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+
+  const uint8_t* d_frames = bgr_frames;
+  const uint8_t* d_prev = prev;
+  unsigned long long* d_out = (unsigned long long*)sums_out;
+  if (mem == EIOKU_MEM_HOST) {
+    size_t total = frame_stride * (size_t)(n - 1) + frame_bytes;
+    uint8_t* din = (uint8_t*)scratch(kSlotIn, total);
+    d_out = (unsigned long long*)scratch(kSlotOut, sizeof(uint64_t) * 3 * n);
+    if (!din || !d_out) return EIOKU_ENOMEM;
+    EIOKU_HIP_CHECK(hipMemcpyAsync(din, bgr_frames, total, hipMemcpyHostToDevice, stream));
+    d_frames = din;
+    if (prev) {
+      uint8_t* dp = (uint8_t*)scratch(kSlotPrev, frame_bytes);
+      if (!dp) return EIOKU_ENOMEM;
+      EIOKU_HIP_CHECK(hipMemcpyAsync(dp, prev, frame_bytes, hipMemcpyHostToDevice, stream));
+      d_prev = dp;
+    }
+  }
+  EIOKU_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint64_t) * 3 * n, stream));
+
+  constexpr int Q = 4;
+  const unsigned long long npix = (unsigned long long)h * w;
+  unsigned long long nquads = npix >> 2;
+  unsigned long long bx = (nquads + (unsigned long long)kBlock * Q - 1) / ((unsigned long long)kBlock * Q);
+  if (bx == 0) bx = 1;
+  int seg = pick_seg(n, bx);
+  dim3 grid((unsigned)bx, (unsigned)((n + seg - 1) / seg));
+  const bool aligned = (((uintptr_t)d_frames | frame_stride | (d_prev ? (uintptr_t)d_prev : 0)) & 3) == 0;
+  if (nquads) {
+    if (aligned) {
+      hipLaunchKernelGGL((k_hsv_sums<Q, true>), grid, dim3(kBlock), 0, stream, d_frames,
+                         frame_stride, n, npix, d_prev, seg, d_out);
+    } else {
+      hipLaunchKernelGGL((k_hsv_sums<Q, false>), grid, dim3(kBlock), 0, stream, d_frames,
+                         frame_stride, n, npix, d_prev, seg, d_out);
+    }
+  }
+  if (npix & 3)
+    hipLaunchKernelGGL(k_hsv_sums_tail, dim3(1), dim3(64), 0, stream, d_frames, frame_stride, n,
+                       nquads << 2, npix, d_prev, d_out);
+  EIOKU_LAUNCH_CHECK();
+  if (mem == EIOKU_MEM_HOST) {
+    EIOKU_HIP_CHECK(hipMemcpyAsync(sums_out, d_out, sizeof(uint64_t) * 3 * n, hipMemcpyDeviceToHost, stream));
+    EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return EIOKU_OK;
+}
+
+int eioku_bgr2hsv(const uint8_t* bgr, size_t n_pixels, uint8_t* hsv_out, int mem, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(mem == EIOKU_MEM_HOST || mem == EIOKU_MEM_DEVICE, "bad mem flag %d", mem);
+  if (n_pixels == 0) return EIOKU_OK;
+  EIOKU_REQUIRE(bgr && hsv_out, "NULL pointer");
+  int rc = ensure_tables();
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const uint8_t* din = bgr;
+  uint8_t* dout = hsv_out;
+  if (mem == EIOKU_MEM_HOST) {
+    uint8_t* a = (uint8_t*)scratch(kSlotIn, n_pixels * 3);
+    uint8_t* b = (uint8_t*)scratch(kSlotOut, n_pixels * 3);
+    if (!a || !b) return EIOKU_ENOMEM;
+    EIOKU_HIP_CHECK(hipMemcpyAsync(a, bgr, n_pixels * 3, hipMemcpyHostToDevice, stream));
+    din = a;
+    dout = b;
+  }
+  unsigned long long g = (n_pixels + kBlock - 1) / kBlock;
+  unsigned long long cap = (unsigned long long)num_cus() * 16;
+  if (g > cap) g = cap;
+  hipLaunchKernelGGL(k_bgr2hsv, dim3((unsigned)g), dim3(kBlock), 0, stream, din,
+                     (unsigned long long)n_pixels, dout);
+  EIOKU_LAUNCH_CHECK();
+  if (mem == EIOKU_MEM_HOST) {
+    EIOKU_HIP_CHECK(hipMemcpyAsync(hsv_out, dout, n_pixels * 3, hipMemcpyDeviceToHost, stream));
+    EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return EIOKU_OK;
+}
+
+}  // extern "C"

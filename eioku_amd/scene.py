@@ -1,0 +1,195 @@
+"""Scene-cut stage: HIP kernels K1/K2 plus the host arithmetic around them.
+
+Mirrors what ``ModelManager.detect_scenes`` observes from its ffmpeg child process
+(``/root/reference/ml-service/src/services/model_manager.py:736-828``) and the PySceneDetect
+``ContentDetector`` that BASELINE.json's north_star names.  The per-frame integer sums come from
+the GPU (``eioku_scene_sad_luma`` / ``eioku_scene_hsv_sums``); everything after them is a handful
+of float64 operations per frame and stays on the host, in the order the libraries perform them.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from ._buffers import current_stream, is_torch, on_device, ptr, same_side
+
+
+def _out_like(ref, shape):
+    if on_device(ref):
+        import torch
+
+        return torch.empty(shape, dtype=torch.int64, device=ref.device)
+    return np.empty(shape, dtype=np.uint64)
+
+
+def _finish(out):
+    """Device results come back as uint64 numpy (one small D2H copy)."""
+    if is_torch(out):
+        return out.cpu().numpy().view(np.uint64)
+    return out
+
+
+def luma_sad(y_frames, prev=None, *, row_stride: int | None = None, frame_stride: int | None = None,
+             shape: tuple[int, int, int] | None = None) -> np.ndarray:
+    """K1: ``sad[t] = sum |Y_t - Y_{t-1}|`` (uint64, exact).  ``sad[0]`` is 0 without ``prev``.
+
+    ``y_frames``: uint8 ``(n,h,w)`` numpy array (host, staged by the library) or CUDA tensor
+    (HBM, zero copy).  ``row_stride`` / ``frame_stride`` / ``shape`` describe padded planes laid
+    out in a flat buffer.
+    """
+    lib = _lib.load()
+    _lib.init()
+    if shape is None:
+        n, h, w = (int(s) for s in y_frames.shape)
+    else:
+        n, h, w = shape
+    row_stride = w if row_stride is None else int(row_stride)
+    frame_stride = row_stride * h if frame_stride is None else int(frame_stride)
+    mem = same_side(y_frames, prev)
+    out = _out_like(y_frames, (n,))
+    _lib.check(lib.eioku_scene_sad_luma(ptr(y_frames), n, h, w, row_stride, frame_stride, ptr(prev),
+                                        ptr(out), mem, current_stream(y_frames)),
+               "eioku_scene_sad_luma")
+    return _finish(out)
+
+
+def hsv_sums(bgr_frames, prev=None) -> np.ndarray:
+    """K2: per-frame ``sum |c_t - c_{t-1}|`` for c in (hue, sat, val); uint64 ``(n,3)``, exact."""
+    lib = _lib.load()
+    _lib.init()
+    n, h, w, c = (int(s) for s in bgr_frames.shape)
+    if c != 3:
+        raise ValueError("expected (n,h,w,3) BGR frames")
+    mem = same_side(bgr_frames, prev)
+    out = _out_like(bgr_frames, (n, 3))
+    _lib.check(lib.eioku_scene_hsv_sums(ptr(bgr_frames), n, h, w, h * w * 3, ptr(prev), ptr(out), mem,
+                                        current_stream(bgr_frames)), "eioku_scene_hsv_sums")
+    return _finish(out)
+
+
+def bgr2hsv(bgr):
+    """OpenCV-compatible 8-bit BGR->HSV image (parity/debug helper)."""
+    lib = _lib.load()
+    _lib.init()
+    if on_device(bgr):
+        import torch
+
+        out = torch.empty_like(bgr)
+    else:
+        out = np.empty_like(bgr)
+    npix = int(np.prod(bgr.shape[:-1]))
+    _lib.check(lib.eioku_bgr2hsv(ptr(bgr), npix, ptr(out), same_side(bgr), current_stream(bgr)),
+               "eioku_bgr2hsv")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# host arithmetic (float64, library order)
+# ---------------------------------------------------------------------------
+
+def ffmpeg_scene_scores(sad: np.ndarray, count: int, *, bitdepth: int = 8, prev_mafd: float = 0.0,
+                        first_has_prev: bool = False):
+    """libavfilter ``get_scene_score`` on the SAD series -> ``(mafd, score)`` float64 arrays.
+
+    ``mafd = sad / count / 2**(bitdepth-8)``; ``score = clip(float32(min(mafd, |mafd - prev|) / 100))``
+    (the value passes through ``av_clipf``, i.e. is rounded to float32).
+    """
+    sad = np.asarray(sad, dtype=np.uint64)
+    mafd = sad.astype(np.float64) / float(count) / float(1 << (bitdepth - 8))
+    prev = np.concatenate(([float(prev_mafd)], mafd[:-1]))
+    q = np.minimum(mafd, np.abs(mafd - prev)) / 100.0
+    score = np.clip(q.astype(np.float32), np.float32(0), np.float32(1)).astype(np.float64)
+    if not first_has_prev and len(score):
+        mafd = mafd.copy()
+        mafd[0] = 0.0
+        score[0] = 0.0
+        if len(score) > 1:  # prev_mafd for frame 1 is still the zero initialisation
+            q1 = min(mafd[1], abs(mafd[1] - float(prev_mafd))) / 100.0
+            score[1] = float(np.clip(np.float32(q1), np.float32(0), np.float32(1)))
+    return mafd, score
+
+
+def pts_time_string(frame_index: int, tb_num: int, tb_den: int, pts_per_frame: int = 1) -> str:
+    """What vf_showinfo prints after ``pts_time:`` - ``"%.6g" % (av_q2d(tb) * pts)``."""
+    return "%.6g" % ((tb_num / float(tb_den)) * (frame_index * pts_per_frame))
+
+
+def content_scores(sums: np.ndarray, num_pixels: int, *, first_has_prev: bool = False) -> np.ndarray:
+    """ContentDetector frame score: ``(dh + ds + dl + 0.0) / 3.0`` with ``d = sum / float(pixels)``."""
+    s = np.asarray(sums, dtype=np.uint64).astype(np.float64) / float(num_pixels)
+    acc = 0.0 + s[:, 0] * 1.0
+    acc = acc + s[:, 1] * 1.0
+    acc = acc + s[:, 2] * 1.0
+    acc = acc + 0.0 * 0.0
+    out = acc / 3.0
+    if not first_has_prev and len(out):
+        out[0] = 0.0
+    return out
+
+
+def content_cuts(scores, threshold: float = 27.0, min_scene_len: int = 15, mode: str = "legacy") -> list[int]:
+    """Cut frames from ContentDetector scores.
+
+    ``legacy``: PySceneDetect 0.6.0-0.6.3 rule (``score >= threshold`` and ``min_scene_len`` frames
+    since the last cut, counting from the first frame); ``suppress`` is the same rule under its
+    0.6.4+ name; ``merge``: the 0.6.4+ ``FlashFilter.Mode.MERGE`` state machine.
+    """
+    scores = np.asarray(scores, dtype=np.float64)
+    n = len(scores)
+    above = scores >= threshold
+    if n:
+        above[0] = False
+    cuts: list[int] = []
+    if mode in ("legacy", "suppress"):
+        last = 0
+        for t in np.nonzero(above)[0]:
+            if t - last >= min_scene_len:
+                cuts.append(int(t))
+                last = int(t)
+        return cuts
+    if mode != "merge":
+        raise ValueError(f"unknown mode {mode!r}")
+    if min_scene_len <= 0:
+        return [int(t) for t in np.nonzero(above)[0]]
+    last_above = 0  # the filter first sees frame 0
+    enabled = triggered = False
+    start = 0
+    for t in range(n):
+        met = (t - last_above) >= min_scene_len
+        if above[t]:
+            last_above = t
+        if triggered:
+            if met and not above[t] and (last_above - start) >= min_scene_len:
+                triggered = False
+                cuts.append(last_above)
+            continue
+        if not above[t]:
+            continue
+        if met:
+            enabled = True
+            cuts.append(t)
+        elif enabled:
+            triggered = True
+            start = t
+    return cuts
+
+
+def build_scenes(cut_timestamps_ms, duration_ms: int | None) -> list[dict]:
+    """The reference's scene list, index quirk included (``model_manager.py:758-828``).
+
+    Cuts t1..tn give ``{i-1: t_i -> t_(i+1)}`` for i < n plus ``{n: tn -> duration}``; no cut gives
+    ``{0: 0 -> duration}``.  ``duration_ms=None`` is the ffprobe-failure fallback (last cut + 1000).
+    """
+    ts = [int(t) for t in cut_timestamps_ms]
+    scenes = [{"scene_index": i, "start_ms": a, "end_ms": b, "duration_ms": b - a}
+              for i, (a, b) in enumerate(zip(ts[:-1], ts[1:]))]
+    last = ts[-1] if ts else 0
+    if duration_ms is None:
+        duration_ms = last + 1000
+    if ts:
+        scenes.append({"scene_index": len(ts), "start_ms": last, "end_ms": duration_ms,
+                       "duration_ms": duration_ms - last})
+    else:
+        scenes.append({"scene_index": 0, "start_ms": 0, "end_ms": duration_ms, "duration_ms": duration_ms})
+    return scenes

@@ -1,0 +1,96 @@
+/*
+ * eioku_hip.h - C ABI of libeioku_hip.so: the MI355X (gfx950) implementation of the
+ * ml-service hot path of codihuston/eioku (scene scoring, YOLOv8 detection,
+ * all-MiniLM-L6-v2 segment embedding, flat-L2 kNN).
+ *
+ * The reference (pure Python, /root/reference @ 2026-01-28) has no FFI for this path:
+ * its arithmetic happens inside ffmpeg / OpenCV / Ultralytics / torchvision calls made
+ * from ml-service/src/services/model_manager.py.  Each entry point below names the
+ * reference call site whose work it replaces, so a maintainer can bind it (ctypes, see
+ * INTEGRATION.md) behind the unchanged ModelManager.detect_* / process_ml_task API.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative EIOKU_E* code; the message for the
+ *     calling thread's last failure is eioku_last_error().
+ *   - `mem` says where the data pointers of THAT call live: EIOKU_MEM_HOST (the library
+ *     stages through its own device buffers; PCIe-inclusive) or EIOKU_MEM_DEVICE (HBM
+ *     pointers, zero copy).  Small result arrays follow the same flag.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls with
+ *     EIOKU_MEM_DEVICE are asynchronous on that stream unless stated; EIOKU_MEM_HOST calls
+ *     return after the results are in the host buffers.
+ *   - handles are thread-compatible: one handle per thread, no internal locking.
+ *   - no callbacks, no torch types, plain pointers and sizes only.
+ */
+#ifndef EIOKU_HIP_H
+#define EIOKU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EIOKU_ABI_VERSION 1
+
+enum {
+  EIOKU_OK = 0,
+  EIOKU_EINVAL = -1,   /* bad argument (shape, alignment, NULL) */
+  EIOKU_ENOMEM = -2,   /* device or host allocation failed */
+  EIOKU_EHIP = -3,     /* a HIP runtime call failed; see eioku_last_error() */
+  EIOKU_ENODEV = -4,   /* no gfx950 device / library not initialised */
+  EIOKU_ESTATE = -5    /* handle used in the wrong state */
+};
+
+enum { EIOKU_MEM_HOST = 0, EIOKU_MEM_DEVICE = 1 };
+
+/* ---- lifecycle ------------------------------------------------------------------------
+ * Replaces: ModelManager._get_device()/gpu_available (model_manager.py:23-42): the Python
+ * host keeps returning "cuda"; this selects the HIP device the worker process is pinned to.
+ */
+int eioku_abi_version(void);
+int eioku_init(int device_id);
+void eioku_shutdown(void);
+const char* eioku_last_error(void);
+/* name, CU count, HBM bytes of the active device (any pointer may be NULL). */
+int eioku_device_info(char* name, size_t name_cap, int* compute_units, uint64_t* hbm_bytes);
+
+/* ---- synthetic inputs (bench / tests) ------------------------------------
+ * Counter-based splitmix64, identical to oracle/prng.py.  Device pointers only.
+ */
+int eioku_synth_u64(uint64_t seed, uint64_t offset, uint64_t n, uint64_t* out_dev, void* stream);
+int eioku_synth_bytes(uint64_t seed, uint64_t n, uint8_t* out_dev, void* stream);
+/* approx-normal float32 (Irwin-Hall 4), optionally L2-normalised per row of `dim`. */
+int eioku_synth_normal_f32(uint64_t seed, uint64_t rows, int dim, int l2_normalise,
+                           float* out_dev, void* stream);
+/* n BGR frames h x w; params_dev = n x 5 int32 {base_b,base_g,base_r,gx,gy}. */
+int eioku_synth_frames_bgr(uint64_t seed, uint64_t first_frame, int n, int h, int w,
+                           const int32_t* params_dev, uint8_t* out_dev, void* stream);
+
+/* ---- scene scoring ---------------------------------------------------------------------
+ * K1. Replaces the `ffmpeg -vf select='gt(scene\,T)',showinfo` child process of
+ * ModelManager.detect_scenes (model_manager.py:736-755): per-frame luma SAD against the
+ * previous frame, exact uint64.  y_frames: n planes of h rows, `row_stride` bytes apart,
+ * planes `frame_stride` bytes apart.  prev (nullable): the plane preceding frame 0 (same
+ * row_stride); without it sad_out[0] = 0.  sad_out: n uint64.
+ */
+int eioku_scene_sad_luma(const uint8_t* y_frames, int n, int h, int w, size_t row_stride,
+                         size_t frame_stride, const uint8_t* prev, uint64_t* sad_out,
+                         int mem, void* stream);
+
+/* K2. PySceneDetect ContentDetector frame deltas (BASELINE.json north_star; the reference
+ * holds intent only, .kiro/specs/semantic-video-search/design.md:59-61): OpenCV 8-bit
+ * BGR->HSV, then per-frame sums of |c_t - c_{t-1}| for c = hue, sat, val, exact uint64.
+ * bgr_frames: n packed frames (h*w*3 bytes each, `frame_stride` bytes apart).
+ * sums_out: n x 3 uint64 (row 0 = 0 unless prev given).
+ */
+int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t frame_stride,
+                         const uint8_t* prev, uint64_t* sums_out, int mem, void* stream);
+
+/* Debug / parity helper: the HSV image itself (same layout as the input). */
+int eioku_bgr2hsv(const uint8_t* bgr, size_t n_pixels, uint8_t* hsv_out, int mem, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EIOKU_HIP_H */

@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the reference's OWN Python code (build container only).
+
+Run:  python tests/golden/make_reference_fixtures.py         (needs /root/reference)
+
+What is pinned here is the reference's orchestration around the third-party calls - the part of
+the hot path that exists as code under /root/reference:
+
+  ref_detect_loop.json   ModelManager.detect_objects / detect_faces
+                         (ml-service/src/services/model_manager.py:215-407) driven with stub
+                         ``cv2`` / ``ultralytics`` modules injected through ``sys.modules``: frame
+                         sampling ``max(1, int(fps*sec))``, ``int(idx/fps*1000)`` timestamps, the
+                         result dict, float32 -> Python float widening, fp32 width/height
+                         subtraction, the face path's extra confidence filter.
+  ref_scenes.json        ModelManager.detect_scenes (model_manager.py:715-835) with
+                         ``subprocess.run`` replaced by scripted ffmpeg/ffprobe output: pts_time
+                         parsing and the scene-list index quirk.
+  ref_artifact_spans.json the span / validation rules of the result -> ArtifactEnvelope mapping
+                         (ml-service/src/domain/artifacts.py:7-73) for rows produced by the path.
+
+Only inputs and outputs are stored (JSON data); no reference source text is copied.
+The stubs stand in for cv2 / ultralytics / ffmpeg *calls*, i.e. the inputs of the orchestration
+under test; the arithmetic inside those libraries is NOT pinned by these fixtures.
+"""
+
+from __future__ import annotations
+
+import asyncio
+import json
+import struct
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REF = Path("/root/reference/ml-service")
+
+
+def f32_bits(x: float) -> int:
+    return struct.unpack("<I", struct.pack("<f", float(x)))[0]
+
+
+def script_boxes(seed: int, frame_idx: int) -> list[dict]:
+    """Deterministic raw detector output for one frame: fp32 xyxy, conf, cls."""
+    rng = np.random.default_rng(seed * 1_000_003 + frame_idx)
+    k = int(rng.integers(0, 4))
+    out = []
+    for _ in range(k):
+        x1, y1 = rng.uniform(0, 1500, 2).astype(np.float32)
+        w, h = rng.uniform(5, 400, 2).astype(np.float32)
+        conf = np.float32(rng.uniform(0.3, 0.99))
+        out.append({"xyxy": [float(x1), float(y1), float(np.float32(x1 + w)), float(np.float32(y1 + h))],
+                    "conf": float(conf), "cls": int(rng.integers(0, 80))})
+    return out
+
+
+def install_stubs(fps: float, total: int, seed: int, names: dict[int, str]):
+    cv2 = types.ModuleType("cv2")
+    cv2.CAP_PROP_FPS = 5
+    cv2.CAP_PROP_FRAME_COUNT = 7
+
+    class VideoCapture:
+        def __init__(self, path):
+            self.pos = 0
+
+        def get(self, prop):
+            return fps if prop == cv2.CAP_PROP_FPS else float(total)
+
+        def read(self):
+            if self.pos >= total:
+                return False, None
+            frame = np.zeros((4, 4, 3), dtype=np.uint8)
+            frame[0, 0, 0] = self.pos & 0xFF
+            frame[0, 0, 1] = (self.pos >> 8) & 0xFF
+            frame[0, 0, 2] = (self.pos >> 16) & 0xFF
+            self.pos += 1
+            return True, frame
+
+        def grab(self):
+            if self.pos >= total:
+                return False
+            self.pos += 1
+            return True
+
+        def release(self):
+            pass
+
+    cv2.VideoCapture = VideoCapture
+
+    ultra = types.ModuleType("ultralytics")
+    calls = []
+
+    class _Box:
+        def __init__(self, b):
+            self.xyxy = torch.tensor([b["xyxy"]], dtype=torch.float32)
+            self.conf = torch.tensor([b["conf"]], dtype=torch.float32)
+            self.cls = torch.tensor([float(b["cls"])], dtype=torch.float32)
+
+    class _Result:
+        def __init__(self, boxes):
+            self.boxes = [_Box(b) for b in boxes]
+            self.names = names
+
+    class YOLO:
+        def __init__(self, path):
+            self.path = path
+
+        def to(self, device):
+            return self
+
+        def __call__(self, frame, conf=0.25, verbose=False, device=None):
+            idx = int(frame[0, 0, 0]) | (int(frame[0, 0, 1]) << 8) | (int(frame[0, 0, 2]) << 16)
+            boxes = script_boxes(seed, idx)
+            calls.append({"frame_index": idx, "conf": conf, "boxes": boxes})
+            # the real predictor drops boxes below `conf` before NMS; keep that contract
+            return [_Result([b for b in boxes if np.float32(b["conf"]) > np.float32(conf)])]
+
+    ultra.YOLO = YOLO
+    sys.modules["cv2"] = cv2
+    sys.modules["ultralytics"] = ultra
+    return calls
+
+
+def capture_detect_loop(ModelManager):
+    names = {i: f"class{i}" for i in range(80)}
+    cases = []
+    specs = [
+        ("objects", 30.0, 200, {"frame_interval": 1}),
+        ("objects", 29.97, 200, {"frame_interval": 3.0, "confidence_threshold": 0.5, "model_name": "yolov8s.pt"}),
+        ("objects", 23.976, 97, {"frame_interval": 0.5, "confidence_threshold": 0.6}),
+        ("objects", 0.0, 65, {}),  # CAP_PROP_FPS == 0 -> `or 30`
+        ("objects", 60.0, 50, {"frame_interval": 0.001}),  # max(1, int(...)) clamp
+        ("faces", 29.97, 200, {}),  # defaults: 3 s, conf 0.7
+        ("faces", 25.0, 120, {"frame_interval": 2, "confidence_threshold": 0.9}),
+        ("objects", 30.0, 0, {}),  # empty video
+    ]
+    for seed, (kind, fps, total, config) in enumerate(specs, start=1):
+        calls = install_stubs(fps, total, seed, names)
+        with tempfile.TemporaryDirectory() as td:
+            mm = ModelManager(cache_dir=td)
+            fn = mm.detect_objects if kind == "objects" else mm.detect_faces
+            result = asyncio.run(fn("/videos/fake.mp4", dict(config)))
+        cases.append({"kind": kind, "fps": fps, "total_frames": total, "config": config, "seed": seed,
+                      "names": {str(k): v for k, v in names.items()},
+                      "detector_calls": calls, "result": result})
+    return cases
+
+
+def capture_scenes(ModelManager):
+    import subprocess
+
+    cases = []
+
+    def showinfo_line(n, pts_time):
+        return (f"[Parsed_showinfo_1 @ 0x5581] n:{n:4d} pts:{n * 512:7d} pts_time:{pts_time:<8} pos:  123 "
+                f"fmt:yuv420p sar:1/1 s:854x480 i:P iskey:0 type:P checksum:0A1B2C3D plane_checksum:[0A1B2C3D]")
+
+    specs = [
+        {"name": "no_cuts", "pts": [], "duration": "30.033000\n", "config": {}},
+        {"name": "one_cut", "pts": ["5.005"], "duration": "30.033000\n", "config": {"threshold": 0.4}},
+        {"name": "three_cuts", "pts": ["4.2042", "12.5125", "20.02"], "duration": "30.033000\n",
+         "config": {"threshold": 0.7, "min_scene_length": 2.0}},
+        {"name": "many_cuts_long", "pts": ["0.0333667", "59.9933", "600.6", "1234.57", "3599.97"],
+         "duration": "3600.000000\n", "config": {}},
+        {"name": "ffprobe_fails", "pts": ["1.5", "2.75"], "duration": "N/A\n", "config": {}},
+        {"name": "malformed_line", "pts": ["1.001", "garbage", "7.5075"], "duration": "10.01\n", "config": {}},
+    ]
+    real_run = subprocess.run
+    for spec in specs:
+        lines = ["ffmpeg version 4.4.2 Copyright (c) 2000-2021", "Input #0, mov,mp4, from 'fake.mp4':"]
+        for n, p in enumerate(spec["pts"]):
+            lines.append(showinfo_line(n, p))
+        lines.append("frame=  900 fps=0.0 q=-0.0 Lsize=N/A time=00:00:30.03 bitrate=N/A")
+        stderr = "\n".join(lines)
+        seen = []
+
+        def fake_run(cmd, capture_output=False, text=False, timeout=None, _spec=spec, _stderr=stderr, _seen=seen):
+            _seen.append(list(cmd))
+            if cmd[0] == "ffmpeg":
+                return types.SimpleNamespace(returncode=0, stdout="", stderr=_stderr)
+            return types.SimpleNamespace(returncode=0, stdout=_spec["duration"], stderr="")
+
+        subprocess.run = fake_run
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                mm = ModelManager(cache_dir=td)
+                result = asyncio.run(mm.detect_scenes("/videos/fake.mp4", dict(spec["config"])))
+        finally:
+            subprocess.run = real_run
+        cases.append({"name": spec["name"], "config": spec["config"], "ffmpeg_stderr": stderr,
+                      "ffprobe_stdout": spec["duration"], "commands": seen, "result": result})
+    return cases
+
+
+def capture_artifact_rules():
+    from src.domain.artifacts import ArtifactEnvelope
+    from datetime import datetime
+
+    rows = []
+    probes = [
+        {"span_start_ms": 0, "span_end_ms": 0},
+        {"span_start_ms": 1000, "span_end_ms": 1000},
+        {"span_start_ms": 5, "span_end_ms": 4},
+        {"span_start_ms": -1, "span_end_ms": 4},
+        {"span_start_ms": 0, "span_end_ms": 10, "schema_version": 0},
+        {"span_start_ms": 0, "span_end_ms": 10, "artifact_id": ""},
+        {"span_start_ms": 0, "span_end_ms": 10, "payload_json": ""},
+        {"span_start_ms": 0, "span_end_ms": 10, "config_hash": "", "input_hash": ""},
+    ]
+    base = dict(artifact_id="v_object_detection_r_0", asset_id="v", artifact_type="object.detection",
+                schema_version=1, span_start_ms=0, span_end_ms=0, payload_json="{}", producer="ml-service",
+                producer_version="1.0.0", model_profile="balanced", config_hash="", input_hash="", run_id="r")
+    for p in probes:
+        kw = dict(base)
+        kw.update(p)
+        try:
+            ArtifactEnvelope(created_at=datetime(2026, 1, 1), **kw)
+            ok, err = True, None
+        except Exception as e:  # noqa: BLE001 - record whatever the reference raises
+            ok, err = False, type(e).__name__
+        rows.append({"fields": kw, "accepted": ok, "error_type": err})
+    return rows
+
+
+def main():
+    if not REF.exists():
+        sys.exit("needs /root/reference (build container only)")
+    sys.path.insert(0, str(REF))
+    from src.services.model_manager import ModelManager
+
+    (HERE / "ref_detect_loop.json").write_text(json.dumps(capture_detect_loop(ModelManager), indent=1))
+    (HERE / "ref_scenes.json").write_text(json.dumps(capture_scenes(ModelManager), indent=1))
+    (HERE / "ref_artifact_spans.json").write_text(json.dumps(capture_artifact_rules(), indent=1))
+    print("wrote fixtures to", HERE)
+
+
+if __name__ == "__main__":
+    main()
