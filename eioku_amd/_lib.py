@@ -31,6 +31,9 @@ SIGNATURES = {
     "eioku_shutdown": (None, []),
     "eioku_last_error": (C.c_char_p, []),
     "eioku_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "eioku_prof_enable": (C.c_int, [C.c_int]),
+    "eioku_prof_reset": (C.c_int, []),
+    "eioku_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "eioku_synth_u64": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "eioku_synth_bytes": (C.c_int, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "eioku_synth_normal_f32": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -60,6 +63,13 @@ def load() -> C.CDLL:
             raise EiokuHipError(
                 f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C eioku_amd/csrc`; there is no CPU fallback for the hot path")
+        # One HIP runtime per process: torch bundles its own libamdhip64 (SONAME libamdhip64.so.7,
+        # the soname this library links against).  Loading torch FIRST makes the dynamic linker
+        # resolve our dependency to that already-loaded copy; the other order leaves two runtimes
+        # in the process and the second one sees no device.  torch owns device memory and streams
+        # for the Python host anyway, so it is always present here.
+        import torch  # noqa: F401
+
         lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
@@ -101,3 +111,22 @@ def device_info() -> dict:
     hbm = C.c_uint64(0)
     check(lib.eioku_device_info(name, 256, C.byref(cus), C.byref(hbm)), "eioku_device_info")
     return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
+
+
+PROF_SCENE_SAD, PROF_SCENE_HSV, PROF_CONV, PROF_KNN, PROF_GEMM = 0, 1, 2, 3, 4
+
+
+def prof_enable(on: bool) -> None:
+    check(load().eioku_prof_enable(int(on)), "eioku_prof_enable")
+
+
+def prof_reset() -> None:
+    check(load().eioku_prof_reset(), "eioku_prof_reset")
+
+
+def prof_read(tag: int) -> tuple[float, int]:
+    """(summed kernel milliseconds, launches) for one tagged kernel since the last reset."""
+    ms = C.c_double(0)
+    cnt = C.c_uint64(0)
+    check(load().eioku_prof_read(tag, C.byref(ms), C.byref(cnt)), "eioku_prof_read")
+    return ms.value, cnt.value

@@ -21,6 +21,10 @@ int num_cus();
 enum ScratchSlot { kSlotIn = 0, kSlotPrev, kSlotOut, kSlotWork0, kSlotWork1, kSlotWork2, kNumSlots };
 void* scratch(ScratchSlot slot, size_t bytes);  // nullptr + error set on failure
 
+// hipEvent brackets around tagged kernel launches (no-ops unless eioku_prof_enable(1)).
+void prof_start(int tag, hipStream_t stream);
+void prof_stop(int tag, hipStream_t stream);
+
 }  // namespace eioku
 
 #define EIOKU_HIP_CHECK(expr)                                                                  \

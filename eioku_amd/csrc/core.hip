@@ -1,8 +1,9 @@
 // Lifecycle, error reporting and scratch memory of libeioku_hip.so.
 #include "common.h"
 
-#include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 namespace eioku {
 
@@ -13,7 +14,29 @@ int g_device = -1;
 int g_cus = 0;
 void* g_scratch[kNumSlots] = {};
 size_t g_scratch_bytes[kNumSlots] = {};
+bool g_prof = false;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events[EIOKU_PROF_NUM_TAGS];
+size_t g_prof_used[EIOKU_PROF_NUM_TAGS] = {};
 }  // namespace
+
+void prof_start(int tag, hipStream_t stream) {
+  if (!g_prof) return;
+  auto& pool = g_prof_events[tag];
+  if (g_prof_used[tag] == pool.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    pool.emplace_back(a, b);
+  }
+  (void)hipEventRecord(pool[g_prof_used[tag]].first, stream);
+}
+
+void prof_stop(int tag, hipStream_t stream) {
+  if (!g_prof) return;
+  auto& pool = g_prof_events[tag];
+  if (g_prof_used[tag] >= pool.size()) return;
+  (void)hipEventRecord(pool[g_prof_used[tag]].second, stream);
+  g_prof_used[tag]++;
+}
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -91,6 +114,31 @@ void eioku_shutdown(void) {
     g_scratch_bytes[i] = 0;
   }
   g_init = false;
+}
+
+int eioku_prof_enable(int on) {
+  g_prof = on != 0;
+  return EIOKU_OK;
+}
+
+int eioku_prof_reset(void) {
+  for (int t = 0; t < EIOKU_PROF_NUM_TAGS; ++t) g_prof_used[t] = 0;
+  return EIOKU_OK;
+}
+
+int eioku_prof_read(int tag, double* total_ms, uint64_t* launches) {
+  EIOKU_REQUIRE(tag >= 0 && tag < EIOKU_PROF_NUM_TAGS, "bad prof tag %d", tag);
+  double total = 0;
+  for (size_t i = 0; i < g_prof_used[tag]; ++i) {
+    auto& ev = g_prof_events[tag][i];
+    EIOKU_HIP_CHECK(hipEventSynchronize(ev.second));
+    float ms = 0;
+    EIOKU_HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
+    total += ms;
+  }
+  if (total_ms) *total_ms = total;
+  if (launches) *launches = g_prof_used[tag];
+  return EIOKU_OK;
 }
 
 int eioku_device_info(char* name, size_t name_cap, int* compute_units, uint64_t* hbm_bytes) {

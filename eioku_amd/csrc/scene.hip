@@ -416,9 +416,12 @@ int eioku_scene_sad_luma(const uint8_t* y_frames, int n, int h, int w, size_t ro
     if (bx == 0) bx = 1;
     int seg = pick_seg(n, bx);
     dim3 grid((unsigned)bx, (unsigned)((n + seg - 1) / seg));
-    if (nvec)
+    if (nvec) {
+      prof_start(EIOKU_PROF_SCENE_SAD, stream);
       hipLaunchKernelGGL(k_sad_luma<U>, grid, dim3(kBlock), 0, stream, d_frames, frame_stride, n,
                          plane, d_prev, seg, d_out);
+      prof_stop(EIOKU_PROF_SCENE_SAD, stream);
+    }
     if (plane & 15)  // ragged tail (< 16 bytes)
       hipLaunchKernelGGL(k_sad_luma_strided, dim3(1, 1), dim3(kBlock), 0, stream, d_frames,
                          frame_stride, row_stride, n, h, w, nvec << 4, d_prev,
@@ -481,6 +484,7 @@ int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t 
   dim3 grid((unsigned)bx, (unsigned)((n + seg - 1) / seg));
   const bool aligned = (((uintptr_t)d_frames | frame_stride | (d_prev ? (uintptr_t)d_prev : 0)) & 3) == 0;
   if (nquads) {
+    prof_start(EIOKU_PROF_SCENE_HSV, stream);
     if (aligned) {
       hipLaunchKernelGGL((k_hsv_sums<Q, true>), grid, dim3(kBlock), 0, stream, d_frames,
                          frame_stride, n, npix, d_prev, seg, d_out);
@@ -488,6 +492,7 @@ int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t 
       hipLaunchKernelGGL((k_hsv_sums<Q, false>), grid, dim3(kBlock), 0, stream, d_frames,
                          frame_stride, n, npix, d_prev, seg, d_out);
     }
+    prof_stop(EIOKU_PROF_SCENE_HSV, stream);
   }
   if (npix & 3)
     hipLaunchKernelGGL(k_hsv_sums_tail, dim3(1), dim3(64), 0, stream, d_frames, frame_stride, n,

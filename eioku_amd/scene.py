@@ -23,15 +23,16 @@ def _out_like(ref, shape):
     return np.empty(shape, dtype=np.uint64)
 
 
-def _finish(out):
-    """Device results come back as uint64 numpy (one small D2H copy)."""
+def _finish(out, keep_on_device=False):
+    """Device results come back as uint64 numpy (one small D2H copy, which synchronises) unless the
+    caller keeps them in HBM (int64 tensor holding the uint64 bits) to stay asynchronous."""
     if is_torch(out):
-        return out.cpu().numpy().view(np.uint64)
+        return out if keep_on_device else out.cpu().numpy().view(np.uint64)
     return out
 
 
 def luma_sad(y_frames, prev=None, *, row_stride: int | None = None, frame_stride: int | None = None,
-             shape: tuple[int, int, int] | None = None) -> np.ndarray:
+             shape: tuple[int, int, int] | None = None, keep_on_device: bool = False) -> np.ndarray:
     """K1: ``sad[t] = sum |Y_t - Y_{t-1}|`` (uint64, exact).  ``sad[0]`` is 0 without ``prev``.
 
     ``y_frames``: uint8 ``(n,h,w)`` numpy array (host, staged by the library) or CUDA tensor
@@ -51,10 +52,10 @@ def luma_sad(y_frames, prev=None, *, row_stride: int | None = None, frame_stride
     _lib.check(lib.eioku_scene_sad_luma(ptr(y_frames), n, h, w, row_stride, frame_stride, ptr(prev),
                                         ptr(out), mem, current_stream(y_frames)),
                "eioku_scene_sad_luma")
-    return _finish(out)
+    return _finish(out, keep_on_device)
 
 
-def hsv_sums(bgr_frames, prev=None) -> np.ndarray:
+def hsv_sums(bgr_frames, prev=None, *, keep_on_device: bool = False) -> np.ndarray:
     """K2: per-frame ``sum |c_t - c_{t-1}|`` for c in (hue, sat, val); uint64 ``(n,3)``, exact."""
     lib = _lib.load()
     _lib.init()
@@ -65,7 +66,7 @@ def hsv_sums(bgr_frames, prev=None) -> np.ndarray:
     out = _out_like(bgr_frames, (n, 3))
     _lib.check(lib.eioku_scene_hsv_sums(ptr(bgr_frames), n, h, w, h * w * 3, ptr(prev), ptr(out), mem,
                                         current_stream(bgr_frames)), "eioku_scene_hsv_sums")
-    return _finish(out)
+    return _finish(out, keep_on_device)
 
 
 def bgr2hsv(bgr):

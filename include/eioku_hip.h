@@ -55,6 +55,23 @@ const char* eioku_last_error(void);
 /* name, CU count, HBM bytes of the active device (any pointer may be NULL). */
 int eioku_device_info(char* name, size_t name_cap, int* compute_units, uint64_t* hbm_bytes);
 
+/* ---- in-library kernel timing (bench.py roofline block) -------------------------------
+ * When enabled, the launch sites of the tagged kernels are bracketed with hipEvents on the
+ * stream they are launched on.  eioku_prof_read synchronises those events and returns the
+ * summed duration and the number of launches since the last reset.
+ */
+enum {
+  EIOKU_PROF_SCENE_SAD = 0,
+  EIOKU_PROF_SCENE_HSV = 1,
+  EIOKU_PROF_CONV = 2,
+  EIOKU_PROF_KNN = 3,
+  EIOKU_PROF_GEMM = 4,
+  EIOKU_PROF_NUM_TAGS = 8
+};
+int eioku_prof_enable(int on);
+int eioku_prof_reset(void);
+int eioku_prof_read(int tag, double* total_ms, uint64_t* launches);
+
 /* ---- synthetic inputs (bench / tests) ------------------------------------
  * Counter-based splitmix64, identical to oracle/prng.py.  Device pointers only.
  */
