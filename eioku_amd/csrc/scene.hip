@@ -234,7 +234,7 @@ __device__ __forceinline__ Quad3 load_quad(const uint8_t* __restrict__ f, unsign
 
 // thread owns Q pixel quads per frame; a workgroup covers Q*256 quads = Q*1024 pixels.
 template <int Q, bool ALIGNED>
-__global__ __launch_bounds__(kBlock) void k_hsv_sums(const uint8_t* __restrict__ frames,
+__global__ __launch_bounds__(kBlock, 4) void k_hsv_sums(const uint8_t* __restrict__ frames,
                                                      size_t frame_stride, int n,
                                                      unsigned long long npix,
                                                      const uint8_t* __restrict__ prev, int seg,
@@ -251,12 +251,15 @@ __global__ __launch_bounds__(kBlock) void k_hsv_sums(const uint8_t* __restrict__
   const int t_begin = blockIdx.y * seg;
   const int t_end = min(n, t_begin + seg);
 
+  // Lanes past the end of the frame read quad 0 (a valid address) and are masked to zero, so
+  // the hot loop has no per-lane branches.
   unsigned long long q[Q];
-  bool live[Q];
+  unsigned mask[Q];
 #pragma unroll
   for (int u = 0; u < Q; ++u) {
     q[u] = ((unsigned long long)blockIdx.x * Q + u) * kBlock + tid;
-    live[u] = q[u] < nquads;
+    mask[u] = q[u] < nquads ? 0xFFFFFFFFu : 0u;
+    if (!mask[u]) q[u] = 0;
   }
 
   unsigned pH[Q], pS[Q], pV[Q];
@@ -265,11 +268,19 @@ __global__ __launch_bounds__(kBlock) void k_hsv_sums(const uint8_t* __restrict__
 #pragma unroll
   for (int u = 0; u < Q; ++u) {
     pH[u] = pS[u] = pV[u] = 0;
-    if (have_prev && live[u]) {
+    if (have_prev) {
       Quad3 d = load_quad<ALIGNED>(pf, q[u]);
       hsv_quad(d.d0, d.d1, d.d2, s_sdiv, s_hdiv, pH[u], pS[u], pV[u]);
+      pH[u] &= mask[u];
+      pS[u] &= mask[u];
+      pV[u] &= mask[u];
     }
   }
+
+  // software pipeline: frame t+1 is in flight while frame t is converted
+  Quad3 cur[Q];
+#pragma unroll
+  for (int u = 0; u < Q; ++u) cur[u] = load_quad<ALIGNED>(frames + (size_t)t_begin * frame_stride, q[u]);
 
   for (int t0 = t_begin; t0 < t_end; t0 += kG) {
     unsigned acc[kG][3];
@@ -279,17 +290,20 @@ __global__ __launch_bounds__(kBlock) void k_hsv_sums(const uint8_t* __restrict__
     for (int k = 0; k < kG; ++k) {
       const int t = t0 + k;
       if (t < t_end) {
-        const uint8_t* f = frames + (size_t)t * frame_stride;
-        Quad3 d[Q];
+        Quad3 nxt[Q];
+        const bool more = t + 1 < t_end;  // wave-uniform
+        if (more) {
+          const uint8_t* f = frames + (size_t)(t + 1) * frame_stride;
 #pragma unroll
-        for (int u = 0; u < Q; ++u) {
-          d[u].d0 = d[u].d1 = d[u].d2 = 0;
-          if (live[u]) d[u] = load_quad<ALIGNED>(f, q[u]);
+          for (int u = 0; u < Q; ++u) nxt[u] = load_quad<ALIGNED>(f, q[u]);
         }
 #pragma unroll
         for (int u = 0; u < Q; ++u) {
-          unsigned H = 0, S = 0, V = 0;
-          if (live[u]) hsv_quad(d[u].d0, d[u].d1, d[u].d2, s_sdiv, s_hdiv, H, S, V);
+          unsigned H, S, V;
+          hsv_quad(cur[u].d0, cur[u].d1, cur[u].d2, s_sdiv, s_hdiv, H, S, V);
+          H &= mask[u];
+          S &= mask[u];
+          V &= mask[u];
           if (have_prev) {
             acc[k][0] = __builtin_amdgcn_sad_u8(H, pH[u], acc[k][0]);
             acc[k][1] = __builtin_amdgcn_sad_u8(S, pS[u], acc[k][1]);
@@ -300,6 +314,10 @@ __global__ __launch_bounds__(kBlock) void k_hsv_sums(const uint8_t* __restrict__
           pV[u] = V;
         }
         have_prev = true;
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < Q; ++u) cur[u] = nxt[u];
+        }
       }
     }
     flush_sums<kG, 3>(acc, s_red, t0, t_end, sums);
@@ -363,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void k_bgr2hsv(const uint8_t* __restrict__ 
 int pick_seg(int n, unsigned long long blocks_x) {
   const unsigned long long want = (unsigned long long)num_cus() * 8;
   int seg = ((n + kG - 1) / kG) * kG;  // one run
-  while (seg > 2 * kG && blocks_x * (unsigned long long)((n + seg - 1) / seg) < want) {
+  while (seg > kG && blocks_x * (unsigned long long)((n + seg - 1) / seg) < want) {
     seg = ((seg / 2 + kG - 1) / kG) * kG;
   }
   return seg < kG ? kG : seg;
@@ -475,7 +493,7 @@ int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t 
   }
   EIOKU_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint64_t) * 3 * n, stream));
 
-  constexpr int Q = 4;
+  constexpr int Q = 2;
   const unsigned long long npix = (unsigned long long)h * w;
   unsigned long long nquads = npix >> 2;
   unsigned long long bx = (nquads + (unsigned long long)kBlock * Q - 1) / ((unsigned long long)kBlock * Q);

@@ -30,7 +30,7 @@ __global__ void k_synth_bytes(unsigned long long seed, unsigned long long n, uin
 __device__ __forceinline__ float irwin_hall4(unsigned long long x) {
   int s = (int)(x & 0xFFFF) + (int)((x >> 16) & 0xFFFF) + (int)((x >> 32) & 0xFFFF) +
           (int)(x >> 48);
-  return (float)(s - 131070) * (1.0f / 37837.22f);
+  return (float)(s - 131070) * (float)(1.0 / 37837.22);  // same constant as np.float32(1.0/37837.22)
 }
 
 // one wave per row; optional L2 normalisation (sum order: lane-strided then xor-tree)
