@@ -1,0 +1,49 @@
+// K4: NHWC fp16 convolution as implicit GEMM on MFMA (gfx950), fused bias + SiLU + residual +
+// concat-slice addressing.  Internal C++ interface used by the YOLOv8 runner and by the raw
+// eioku_conv2d_f16 test entry point.
+#pragma once
+
+#include <hip/hip_fp16.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "common.h"
+
+namespace eioku {
+
+// A tensor is an NHWC fp16 buffer; a *slice* is `C` channels starting at channel `coff` of a buffer
+// whose pixels are `cstride` channels apart (this is how concat / chunk are expressed: no copies).
+struct Slice {
+  __half* ptr = nullptr;
+  int cstride = 0;
+  int coff = 0;
+};
+
+struct ConvWeights {
+  int cout = 0, cin = 0, ks = 1, stride = 1;
+  int nf = 1;       // 16-wide cout fragments per workgroup tile
+  int ntiles = 0;   // cout tiles = ceil(cout / (16*nf))
+  int nchunks = 0;  // 32-channel input chunks = ceil(cin / 32)
+  __half* d_w = nullptr;  // [ntiles][nchunks][taps][16*nf][32] fp16, zero padded
+  float* d_b = nullptr;   // [ntiles*16*nf] fp32, zero padded
+  double flops_per_pixel() const { return 2.0 * cout * cin * ks * ks; }
+};
+
+// Packs torch-layout fp32 weights [cout][cin][ks][ks] (+ bias[cout], may be null) for the kernel
+// and uploads them.  Values are rounded to fp16 (RNE) exactly as `tensor.half()` does.
+int conv_weights_create(ConvWeights* cw, int cout, int cin, int ks, int stride, const float* w,
+                        const float* b);
+void conv_weights_destroy(ConvWeights* cw);
+
+enum ConvAct { kActNone = 0, kActSiLU = 1 };
+
+// out = act(conv(in) + bias) [+ res]; output fp16 into `out`, or fp32 into `out_f32` (dense
+// [N,Ho,Wo,cout]) when out_f32 != nullptr.  H, W: input size; output is ceil-free standard
+// (H + 2*pad - ks)/stride + 1 with pad = ks/2.
+int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out, float* out_f32,
+                 Slice res, int act, hipStream_t stream);
+
+inline int conv_out_dim(int x, int ks, int stride) { return (x + 2 * (ks / 2) - ks) / stride + 1; }
+
+}  // namespace eioku

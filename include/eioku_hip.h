@@ -107,6 +107,24 @@ int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t 
 /* Debug / parity helper: the HSV image itself (same layout as the input). */
 int eioku_bgr2hsv(const uint8_t* bgr, size_t n_pixels, uint8_t* hsv_out, int mem, void* stream);
 
+/* ---- detection: YOLOv8 -----------------------------------------------------------------
+ * K4 building block.  One NHWC fp16 convolution (k in {1,3}, stride in {1,2} (2 only for k=3),
+ * pad k/2) as implicit GEMM on MFMA with fused bias + optional SiLU + optional residual.  This is
+ * the arithmetic that `model(frame, ...)` (ultralytics, called at model_manager.py:270-275 and
+ * :364-369) spends its time in (Conv2d + folded BatchNorm + SiLU).  Device pointers only.
+ *   in_nhwc   : fp16, n x h x w pixels, `in_cstride` channels per pixel; the conv reads the `cin`
+ *               channels starting at `in_coff` (a concat/chunk slice).  cin, strides, offsets % 8 == 0.
+ *   weight    : HOST fp32 [cout][cin][k][k] (torch layout), bias HOST fp32 [cout] or NULL; rounded
+ *               to fp16 like tensor.half().
+ *   residual  : optional fp16 slice added after activation: out = fp16(fp16(act(..)) + res).
+ *   out_nhwc  : fp16 slice (cstride/coff % 4 == 0), or out_f32 != NULL: dense fp32 [n,ho,wo,cout].
+ * Synchronous (packs weights per call): a test / building-block entry, not the fast path.
+ */
+int eioku_conv2d_f16(const void* in_nhwc, int n, int h, int w, int in_cstride, int in_coff, int cin,
+                     const float* weight_oihw, const float* bias, int cout, int ksize, int stride,
+                     int act_silu, const void* residual, int res_cstride, int res_coff,
+                     void* out_nhwc, int out_cstride, int out_coff, float* out_f32, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
