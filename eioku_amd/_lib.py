@@ -48,6 +48,23 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p]),
+    "eioku_yolo_create": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "eioku_yolo_destroy": (None, [C.c_void_p]),
+    "eioku_yolo_num_convs": (C.c_int, [C.c_void_p]),
+    "eioku_yolo_conv_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "eioku_yolo_set_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "eioku_yolo_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_void_p), C.c_void_p]),
+    "eioku_yolo_last_conv_flops": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "eioku_yolo_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "eioku_letterbox_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eioku_yolo_postprocess": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

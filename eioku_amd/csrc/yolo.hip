@@ -1,0 +1,504 @@
+// YOLOv8 detection runner: builds the layer plan of the Ultralytics yolov8{n,s,m,l,x}[-face] graph
+// over NHWC fp16 buffers (concat / chunk expressed as channel slices, never copied) and runs
+// letterbox -> backbone/neck/head convs (K4) -> decode (K6) -> NMS (K7) on one HIP stream.
+//
+// Graph (ultralytics/cfg/models/v8/yolov8.yaml; ch = backbone widths c1..c5, d = C2f repeats):
+//   0 Conv(3,c1,3,2) 1 Conv(c1,c2,3,2) 2 C2f(c2,c2,d0,sc) 3 Conv(c2,c3,3,2) 4 C2f(c3,c3,d1,sc)
+//   5 Conv(c3,c4,3,2) 6 C2f(c4,c4,d2,sc) 7 Conv(c4,c5,3,2) 8 C2f(c5,c5,d3,sc) 9 SPPF(c5,c5,5)
+//   10 Up 11 Cat(10,6) 12 C2f(c5+c4,c4,d0) 13 Up 14 Cat(13,4) 15 C2f(c4+c3,c3,d0)
+//   16 Conv(c3,c3,3,2) 17 Cat(16,12) 18 C2f(c3+c4,c4,d0) 19 Conv(c4,c4,3,2) 20 Cat(19,9)
+//   21 C2f(c4+c5,c5,d0) 22 Detect(nc; P3=15,P4=18,P5=21)
+#include <algorithm>
+#include <array>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "yolo_ops.h"
+
+using namespace eioku;
+
+namespace {
+
+constexpr int kRegMax = 16;
+
+struct Buf {
+  int level;  // 0 = input resolution, k = H / 2^k
+  int ch;
+  __half* ptr = nullptr;
+  size_t cap = 0;  // bytes
+};
+
+enum OpKind { kConv, kPool, kUp };
+
+struct Op {
+  OpKind kind;
+  int conv = -1;  // weight index
+  int in_buf, in_off, in_ch;
+  int out_buf, out_off;
+  int res_buf = -1, res_off = 0;
+  int act = kActSiLU;
+  int f32_out = -1;  // index into head outputs (0..5) or -1
+};
+
+}  // namespace
+
+struct eioku_yolo {
+  int ch[5], depth[4], nc;
+  std::vector<std::string> names;
+  std::vector<std::array<int, 4>> shapes;  // cout, cin, k, stride
+  std::vector<ConvWeights> weights;
+  std::vector<bool> set;
+  std::vector<Buf> bufs;
+  std::vector<Op> ops;
+  int in_buf = -1;
+  int head_src[3];
+  // per-shape workspace
+  int cur_n = 0, cur_h = 0, cur_w = 0;
+  float* head[6] = {};  // box P3,P4,P5 ; cls P3,P4,P5 (fp32)
+  size_t head_cap[6] = {};
+  Cand* cands = nullptr;  // dense [N][A] followed by keys [N][A]
+  size_t cands_cap = 0;
+  int32_t* counts = nullptr;  // [N] cand counts + [N] det counts
+  size_t counts_cap = 0;
+  Det* dets = nullptr;
+  size_t dets_cap = 0;
+  // letterbox tables
+  void* lb_tables = nullptr;
+  size_t lb_cap = 0;
+  __half* lb_out = nullptr;  // == bufs[in_buf].ptr
+  double conv_flops_last = 0;
+};
+
+namespace {
+
+int add_buf(eioku_yolo* y, int level, int ch) {
+  y->bufs.push_back(Buf{level, ch});
+  return (int)y->bufs.size() - 1;
+}
+
+int add_conv_w(eioku_yolo* y, const std::string& name, int cout, int cin, int k, int s) {
+  y->names.push_back(name);
+  y->shapes.push_back({cout, cin, k, s});
+  return (int)y->names.size() - 1;
+}
+
+void add_conv(eioku_yolo* y, const std::string& name, int cin, int cout, int k, int s, int in_buf, int in_off,
+              int out_buf, int out_off, int res_buf = -1, int res_off = 0, int act = kActSiLU, int f32_out = -1) {
+  Op op;
+  op.kind = kConv;
+  op.conv = add_conv_w(y, name, cout, cin, k, s);
+  op.in_buf = in_buf;
+  op.in_off = in_off;
+  op.in_ch = cin;
+  op.out_buf = out_buf;
+  op.out_off = out_off;
+  op.res_buf = res_buf;
+  op.res_off = res_off;
+  op.act = act;
+  op.f32_out = f32_out;
+  y->ops.push_back(op);
+}
+
+// C2f(c1 -> c2, n bottlenecks, shortcut): input slice (in_buf,in_off,c1) -> output slice (out_buf,out_off)
+void add_c2f(eioku_yolo* y, const std::string& p, int level, int c1, int c2, int n, bool shortcut, int in_buf,
+             int in_off, int out_buf, int out_off) {
+  const int c = c2 / 2;
+  const int cat = add_buf(y, level, (2 + n) * c);
+  const int tmp = add_buf(y, level, c);
+  add_conv(y, p + ".cv1.conv", c1, 2 * c, 1, 1, in_buf, in_off, cat, 0);
+  for (int i = 0; i < n; ++i) {
+    const std::string m = p + ".m." + std::to_string(i);
+    add_conv(y, m + ".cv1.conv", c, c, 3, 1, cat, (1 + i) * c, tmp, 0);
+    add_conv(y, m + ".cv2.conv", c, c, 3, 1, tmp, 0, cat, (2 + i) * c, shortcut ? cat : -1, (1 + i) * c);
+  }
+  add_conv(y, p + ".cv2.conv", (2 + n) * c, c2, 1, 1, cat, 0, out_buf, out_off);
+}
+
+void build_graph(eioku_yolo* y) {
+  const int c1 = y->ch[0], c2 = y->ch[1], c3 = y->ch[2], c4 = y->ch[3], c5 = y->ch[4];
+  const int d0 = y->depth[0], d1 = y->depth[1], d2 = y->depth[2], d3 = y->depth[3];
+  y->in_buf = add_buf(y, 0, 8);  // RGB + 5 zero channels (16-byte pixel)
+  const int t0 = add_buf(y, 1, c1), t1 = add_buf(y, 2, c2), t2 = add_buf(y, 2, c2);
+  const int t3 = add_buf(y, 3, c3), t5 = add_buf(y, 4, c4), t7 = add_buf(y, 5, c5), t8 = add_buf(y, 5, c5);
+  const int cat14 = add_buf(y, 3, c4 + c3);  // [up(12) | out4]
+  const int cat11 = add_buf(y, 4, c5 + c4);  // [up(9)  | out6]
+  const int cat20 = add_buf(y, 5, c4 + c5);  // [conv19 | out9]
+  const int cat17 = add_buf(y, 4, c3 + c4);  // [conv16 | out12]
+  const int sppf = add_buf(y, 5, 2 * c5);    // [cv1 | m1 | m2 | m3], c5/2 each
+  const int t15 = add_buf(y, 3, c3), t18 = add_buf(y, 4, c4), t21 = add_buf(y, 5, c5);
+
+  add_conv(y, "model.0.conv", 8, c1, 3, 2, y->in_buf, 0, t0, 0);
+  add_conv(y, "model.1.conv", c1, c2, 3, 2, t0, 0, t1, 0);
+  add_c2f(y, "model.2", 2, c2, c2, d0, true, t1, 0, t2, 0);
+  add_conv(y, "model.3.conv", c2, c3, 3, 2, t2, 0, t3, 0);
+  add_c2f(y, "model.4", 3, c3, c3, d1, true, t3, 0, cat14, c4);
+  add_conv(y, "model.5.conv", c3, c4, 3, 2, cat14, c4, t5, 0);
+  add_c2f(y, "model.6", 4, c4, c4, d2, true, t5, 0, cat11, c5);
+  add_conv(y, "model.7.conv", c4, c5, 3, 2, cat11, c5, t7, 0);
+  add_c2f(y, "model.8", 5, c5, c5, d3, true, t7, 0, t8, 0);
+  // SPPF
+  const int ch = c5 / 2;
+  add_conv(y, "model.9.cv1.conv", c5, ch, 1, 1, t8, 0, sppf, 0);
+  for (int i = 0; i < 3; ++i) {
+    Op op;
+    op.kind = kPool;
+    op.in_buf = sppf;
+    op.in_off = i * ch;
+    op.in_ch = ch;
+    op.out_buf = sppf;
+    op.out_off = (i + 1) * ch;
+    y->ops.push_back(op);
+  }
+  add_conv(y, "model.9.cv2.conv", 4 * ch, c5, 1, 1, sppf, 0, cat20, c4);
+  // neck
+  auto add_up = [&](int in_buf, int in_off, int chn, int out_buf, int out_off) {
+    Op op;
+    op.kind = kUp;
+    op.in_buf = in_buf;
+    op.in_off = in_off;
+    op.in_ch = chn;
+    op.out_buf = out_buf;
+    op.out_off = out_off;
+    y->ops.push_back(op);
+  };
+  add_up(cat20, c4, c5, cat11, 0);
+  add_c2f(y, "model.12", 4, c5 + c4, c4, d0, false, cat11, 0, cat17, c3);
+  add_up(cat17, c3, c4, cat14, 0);
+  add_c2f(y, "model.15", 3, c4 + c3, c3, d0, false, cat14, 0, t15, 0);
+  add_conv(y, "model.16.conv", c3, c3, 3, 2, t15, 0, cat17, 0);
+  add_c2f(y, "model.18", 4, c3 + c4, c4, d0, false, cat17, 0, t18, 0);
+  add_conv(y, "model.19.conv", c4, c4, 3, 2, t18, 0, cat20, 0);
+  add_c2f(y, "model.21", 5, c4 + c5, c5, d0, false, cat20, 0, t21, 0);
+  // Detect
+  const int cb = std::max(std::max(16, c3 / 4), kRegMax * 4);
+  const int cc = std::max(c3, std::min(y->nc, 100));
+  const int src[3] = {t15, t18, t21};
+  const int srcc[3] = {c3, c4, c5};
+  for (int l = 0; l < 3; ++l) {
+    y->head_src[l] = src[l];
+    const int lvl = 3 + l;
+    const std::string i = std::to_string(l);
+    const int b1 = add_buf(y, lvl, cb), b2 = add_buf(y, lvl, cb), k1 = add_buf(y, lvl, cc), k2 = add_buf(y, lvl, cc);
+    add_conv(y, "model.22.cv2." + i + ".0.conv", srcc[l], cb, 3, 1, src[l], 0, b1, 0);
+    add_conv(y, "model.22.cv2." + i + ".1.conv", cb, cb, 3, 1, b1, 0, b2, 0);
+    add_conv(y, "model.22.cv2." + i + ".2", cb, 4 * kRegMax, 1, 1, b2, 0, -1, 0, -1, 0, kActNone, l);
+    add_conv(y, "model.22.cv3." + i + ".0.conv", srcc[l], cc, 3, 1, src[l], 0, k1, 0);
+    add_conv(y, "model.22.cv3." + i + ".1.conv", cc, cc, 3, 1, k1, 0, k2, 0);
+    add_conv(y, "model.22.cv3." + i + ".2", cc, y->nc, 1, 1, k2, 0, -1, 0, -1, 0, kActNone, 3 + l);
+  }
+  y->weights.resize(y->names.size());
+  y->set.assign(y->names.size(), false);
+}
+
+int level_dim(int x, int level) {
+  for (int i = 0; i < level; ++i) x = conv_out_dim(x, 3, 2);
+  return x;
+}
+
+template <typename T>
+int ensure(T** p, size_t* cap, size_t bytes) {
+  if (*cap >= bytes) return EIOKU_OK;
+  if (*p) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+  }
+  EIOKU_HIP_CHECK(hipMalloc((void**)p, bytes));
+  *cap = bytes;
+  return EIOKU_OK;
+}
+
+int prepare(eioku_yolo* y, int n, int h, int w) {
+  EIOKU_REQUIRE(h % 32 == 0 && w % 32 == 0, "network input %dx%d must be a multiple of 32", h, w);
+  for (auto& b : y->bufs) {
+    const size_t bytes = (size_t)n * level_dim(h, b.level) * level_dim(w, b.level) * b.ch * sizeof(__half);
+    int rc = ensure(&b.ptr, &b.cap, bytes);
+    if (rc) return rc;
+  }
+  int A = 0;
+  for (int l = 0; l < 3; ++l) {
+    const size_t px = (size_t)n * level_dim(h, 3 + l) * level_dim(w, 3 + l);
+    A += level_dim(h, 3 + l) * level_dim(w, 3 + l);
+    int rc = ensure(&y->head[l], &y->head_cap[l], px * 4 * kRegMax * sizeof(float));
+    if (rc) return rc;
+    rc = ensure(&y->head[3 + l], &y->head_cap[3 + l], px * y->nc * sizeof(float));
+    if (rc) return rc;
+  }
+  int rc = ensure(&y->cands, &y->cands_cap, (size_t)n * A * (sizeof(Cand) + sizeof(unsigned long long)));
+  if (rc) return rc;
+  rc = ensure(&y->counts, &y->counts_cap, (size_t)n * 2 * sizeof(int32_t));
+  if (rc) return rc;
+  y->cur_n = n;
+  y->cur_h = h;
+  y->cur_w = w;
+  return EIOKU_OK;
+}
+
+int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream) {
+  for (size_t i = 0; i < y->set.size(); ++i)
+    EIOKU_REQUIRE(y->set[i], "conv %zu (%s) has no weights", i, y->names[i].c_str());
+  double flops = 0;
+  for (const Op& op : y->ops) {
+    const Buf& ib = y->bufs[op.in_buf];
+    const int H = level_dim(h, ib.level), W = level_dim(w, ib.level);
+    Slice in{ib.ptr, ib.ch, op.in_off};
+    int rc = EIOKU_OK;
+    if (op.kind == kConv) {
+      const ConvWeights& cw = y->weights[op.conv];
+      Slice out{}, res{};
+      float* f32 = nullptr;
+      if (op.f32_out >= 0) {
+        f32 = y->head[op.f32_out];
+      } else {
+        const Buf& ob = y->bufs[op.out_buf];
+        out = Slice{ob.ptr, ob.ch, op.out_off};
+      }
+      if (op.res_buf >= 0) res = Slice{y->bufs[op.res_buf].ptr, y->bufs[op.res_buf].ch, op.res_off};
+      rc = conv_forward(cw, in, n, H, W, out, f32, res, op.act, stream);
+      flops += cw.flops_per_pixel() * n * conv_out_dim(H, cw.ks, cw.stride) * conv_out_dim(W, cw.ks, cw.stride);
+    } else if (op.kind == kPool) {
+      const Buf& ob = y->bufs[op.out_buf];
+      rc = maxpool5_forward(in, Slice{ob.ptr, ob.ch, op.out_off}, n, H, W, op.in_ch, stream);
+    } else {
+      const Buf& ob = y->bufs[op.out_buf];
+      rc = upsample2x_forward(in, Slice{ob.ptr, ob.ch, op.out_off}, n, H, W, op.in_ch, stream);
+    }
+    if (rc) return rc;
+  }
+  y->conv_flops_last = flops;
+  return EIOKU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eioku_yolo_create(const int* ch5, const int* depth4, int nc, eioku_yolo** out) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(ch5 && depth4 && out, "NULL argument");
+  EIOKU_REQUIRE(nc >= 1 && nc <= 1024, "nc %d out of range", nc);
+  for (int i = 0; i < 5; ++i) EIOKU_REQUIRE(ch5[i] >= 16 && ch5[i] % 16 == 0, "width ch[%d]=%d must be a multiple of 16", i, ch5[i]);
+  for (int i = 0; i < 4; ++i) EIOKU_REQUIRE(depth4[i] >= 1 && depth4[i] <= 12, "depth[%d]=%d out of range", i, depth4[i]);
+  auto* y = new eioku_yolo();
+  for (int i = 0; i < 5; ++i) y->ch[i] = ch5[i];
+  for (int i = 0; i < 4; ++i) y->depth[i] = depth4[i];
+  y->nc = nc;
+  build_graph(y);
+  *out = y;
+  return EIOKU_OK;
+}
+
+void eioku_yolo_destroy(eioku_yolo* y) {
+  if (!y) return;
+  (void)hipDeviceSynchronize();
+  for (auto& w : y->weights) conv_weights_destroy(&w);
+  for (auto& b : y->bufs)
+    if (b.ptr) (void)hipFree(b.ptr);
+  for (int i = 0; i < 6; ++i)
+    if (y->head[i]) (void)hipFree(y->head[i]);
+  if (y->cands) (void)hipFree(y->cands);
+  if (y->counts) (void)hipFree(y->counts);
+  if (y->dets) (void)hipFree(y->dets);
+  if (y->lb_tables) (void)hipFree(y->lb_tables);
+  delete y;
+}
+
+int eioku_yolo_num_convs(const eioku_yolo* y) { return y ? (int)y->names.size() : 0; }
+
+int eioku_yolo_conv_info(const eioku_yolo* y, int idx, char* name, size_t cap, int* cout, int* cin, int* k,
+                         int* stride) {
+  EIOKU_REQUIRE(y && idx >= 0 && idx < (int)y->names.size(), "bad conv index %d", idx);
+  if (name && cap) snprintf(name, cap, "%s", y->names[idx].c_str());
+  if (cout) *cout = y->shapes[idx][0];
+  if (cin) *cin = y->shapes[idx][1];
+  if (k) *k = y->shapes[idx][2];
+  if (stride) *stride = y->shapes[idx][3];
+  return EIOKU_OK;
+}
+
+int eioku_yolo_set_conv(eioku_yolo* y, int idx, const float* w_oihw, const float* bias) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(y && idx >= 0 && idx < (int)y->names.size(), "bad conv index %d", idx);
+  EIOKU_REQUIRE(w_oihw, "NULL weights");
+  const auto& s = y->shapes[idx];
+  if (y->set[idx]) conv_weights_destroy(&y->weights[idx]);
+  int rc = conv_weights_create(&y->weights[idx], s[0], s[1], s[2], s[3], w_oihw, bias);
+  y->set[idx] = rc == EIOKU_OK;
+  return rc;
+}
+
+int eioku_yolo_forward(eioku_yolo* y, const void* in_nhwc8, int n, int h, int w, float* const* box_out,
+                       float* const* cls_out, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(y && in_nhwc8, "NULL argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = prepare(y, n, h, w);
+  if (rc) return rc;
+  EIOKU_HIP_CHECK(hipMemcpyAsync(y->bufs[y->in_buf].ptr, in_nhwc8, (size_t)n * h * w * 8 * sizeof(__half),
+                                 hipMemcpyDeviceToDevice, stream));
+  rc = run_network(y, n, h, w, stream);
+  if (rc) return rc;
+  for (int l = 0; l < 3; ++l) {
+    const size_t px = (size_t)n * level_dim(h, 3 + l) * level_dim(w, 3 + l);
+    if (box_out && box_out[l])
+      EIOKU_HIP_CHECK(hipMemcpyAsync(box_out[l], y->head[l], px * 64 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (cls_out && cls_out[l])
+      EIOKU_HIP_CHECK(hipMemcpyAsync(cls_out[l], y->head[3 + l], px * y->nc * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  }
+  return EIOKU_OK;
+}
+
+int eioku_yolo_last_conv_flops(const eioku_yolo* y, double* flops) {
+  EIOKU_REQUIRE(y && flops, "NULL argument");
+  *flops = y->conv_flops_last;
+  return EIOKU_OK;
+}
+
+// Detection from raw frames.  The letterbox tables (xofs/yofs/xalpha/ybeta and the geometry) are
+// computed by the host in the reference's own Python float semantics and passed in `lb`:
+//   lb_geom[0..8] = {new_h, new_w, top, left, out_h, out_w, mode, pad_x, pad_y}
+// (pad_x/pad_y are scale_boxes' own rounding of the padding, which need not equal left/top).
+int eioku_yolo_detect(eioku_yolo* y, const uint8_t* bgr, int n, int h, int w, const int32_t* lb_geom,
+                      const int32_t* xofs, const int32_t* yofs, const int16_t* xalpha, const int16_t* ybeta,
+                      float gain, float conf, float iou, int max_det, void* dets_out, int32_t* counts_out,
+                      int mem, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(y && lb_geom, "NULL argument");
+  EIOKU_REQUIRE(mem == EIOKU_MEM_HOST || mem == EIOKU_MEM_DEVICE, "bad mem flag %d", mem);
+  EIOKU_REQUIRE(n >= 0 && h > 0 && w > 0, "bad frame shape");
+  if (n == 0) return EIOKU_OK;
+  EIOKU_REQUIRE(bgr && dets_out && counts_out, "NULL buffer");
+  hipStream_t stream = (hipStream_t)stream_;
+  LetterboxPlan p;
+  p.src_h = h;
+  p.src_w = w;
+  p.new_h = lb_geom[0];
+  p.new_w = lb_geom[1];
+  p.top = lb_geom[2];
+  p.left = lb_geom[3];
+  p.out_h = lb_geom[4];
+  p.out_w = lb_geom[5];
+  p.mode = lb_geom[6];
+  EIOKU_REQUIRE(p.mode >= 0 && p.mode <= 2, "bad letterbox mode %d", p.mode);
+  EIOKU_REQUIRE(p.new_h > 0 && p.new_w > 0 && p.top >= 0 && p.left >= 0 && p.top + p.new_h <= p.out_h &&
+                    p.left + p.new_w <= p.out_w, "inconsistent letterbox geometry");
+  EIOKU_REQUIRE(p.mode != 1 || (xofs && yofs && xalpha && ybeta), "bilinear letterbox needs its tables");
+  EIOKU_REQUIRE(p.mode != 0 || (p.new_h == h && p.new_w == w), "copy mode needs new size == source size");
+  EIOKU_REQUIRE(p.mode != 2 || (p.new_h * 2 == h && p.new_w * 2 == w), "area mode needs an exact 1/2 scale");
+  int rc = prepare(y, n, p.out_h, p.out_w);
+  if (rc) return rc;
+  // tables -> device
+  const size_t tb = (size_t)p.new_w * 4 + (size_t)p.new_h * 4 + (size_t)p.new_w * 4 + (size_t)p.new_h * 4;
+  rc = ensure(&y->lb_tables, &y->lb_cap, tb + 64);
+  if (rc) return rc;
+  char* t = (char*)y->lb_tables;
+  p.xofs = (const int32_t*)t;
+  p.yofs = (const int32_t*)(t + (size_t)p.new_w * 4);
+  p.xalpha = (const int16_t*)(t + (size_t)p.new_w * 4 + (size_t)p.new_h * 4);
+  p.ybeta = (const int16_t*)(t + (size_t)p.new_w * 8 + (size_t)p.new_h * 4);
+  if (p.mode == 1) {
+    for (int i = 0; i < p.new_w; ++i) EIOKU_REQUIRE(xofs[i] >= 0 && xofs[i] < w, "xofs[%d]=%d outside the frame", i, xofs[i]);
+    EIOKU_HIP_CHECK(hipMemcpyAsync((void*)p.xofs, xofs, (size_t)p.new_w * 4, hipMemcpyHostToDevice, stream));
+    EIOKU_HIP_CHECK(hipMemcpyAsync((void*)p.yofs, yofs, (size_t)p.new_h * 4, hipMemcpyHostToDevice, stream));
+    EIOKU_HIP_CHECK(hipMemcpyAsync((void*)p.xalpha, xalpha, (size_t)p.new_w * 4, hipMemcpyHostToDevice, stream));
+    EIOKU_HIP_CHECK(hipMemcpyAsync((void*)p.ybeta, ybeta, (size_t)p.new_h * 4, hipMemcpyHostToDevice, stream));
+  }
+  const uint8_t* d_bgr = bgr;
+  if (mem == EIOKU_MEM_HOST) {
+    uint8_t* s = (uint8_t*)scratch(kSlotIn, (size_t)n * h * w * 3);
+    if (!s) return EIOKU_ENOMEM;
+    EIOKU_HIP_CHECK(hipMemcpyAsync(s, bgr, (size_t)n * h * w * 3, hipMemcpyHostToDevice, stream));
+    d_bgr = s;
+  }
+  rc = letterbox_forward(d_bgr, n, p, y->bufs[y->in_buf].ptr, stream);
+  if (rc) return rc;
+  rc = run_network(y, n, p.out_h, p.out_w, stream);
+  if (rc) return rc;
+
+  int Hl[3], Wl[3], A = 0;
+  for (int l = 0; l < 3; ++l) {
+    Hl[l] = level_dim(p.out_h, 3 + l);
+    Wl[l] = level_dim(p.out_w, 3 + l);
+    A += Hl[l] * Wl[l];
+  }
+  rc = ensure(&y->dets, &y->dets_cap, (size_t)n * max_det * sizeof(Det));
+  if (rc) return rc;
+  EIOKU_HIP_CHECK(hipMemsetAsync(y->counts, 0, (size_t)n * 2 * sizeof(int32_t), stream));
+  const float* box[3] = {y->head[0], y->head[1], y->head[2]};
+  const float* cls[3] = {y->head[3], y->head[4], y->head[5]};
+  rc = decode_forward(box, cls, n, Hl, Wl, y->nc, conf, y->cands, y->counts, A, stream);
+  if (rc) return rc;
+  ScaleParams sp;
+  sp.gain = gain;
+  sp.pad_x = (float)lb_geom[7];
+  sp.pad_y = (float)lb_geom[8];
+  sp.src_w = (float)w;
+  sp.src_h = (float)h;
+  rc = nms_forward(y->cands, y->counts, n, A, iou, max_det, 7680.0f, sp, y->dets, y->counts + n, stream);
+  if (rc) return rc;
+  const hipMemcpyKind kind = mem == EIOKU_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  EIOKU_HIP_CHECK(hipMemcpyAsync(dets_out, y->dets, (size_t)n * max_det * sizeof(Det), kind, stream));
+  EIOKU_HIP_CHECK(hipMemcpyAsync(counts_out, y->counts + n, (size_t)n * sizeof(int32_t), kind, stream));
+  if (mem == EIOKU_MEM_HOST) EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
+  return EIOKU_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone stage entry points (parity tests; callers that own their own network)
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int eioku_letterbox_f16(const uint8_t* bgr_dev, int n, int h, int w, const int32_t* lb_geom, const int32_t* xofs,
+                        const int32_t* yofs, const int16_t* xalpha, const int16_t* ybeta, void* out_nhwc8_dev,
+                        void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(lb_geom && (n == 0 || (bgr_dev && out_nhwc8_dev)), "NULL argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  LetterboxPlan p;
+  p.src_h = h; p.src_w = w;
+  p.new_h = lb_geom[0]; p.new_w = lb_geom[1]; p.top = lb_geom[2]; p.left = lb_geom[3];
+  p.out_h = lb_geom[4]; p.out_w = lb_geom[5]; p.mode = lb_geom[6];
+  EIOKU_REQUIRE(p.mode >= 0 && p.mode <= 2, "bad letterbox mode %d", p.mode);
+  EIOKU_REQUIRE(p.mode != 1 || (xofs && yofs && xalpha && ybeta), "bilinear letterbox needs its tables");
+  char* t = (char*)scratch(kSlotWork0, (size_t)(p.new_w + p.new_h) * 8 + 64);
+  if (!t) return EIOKU_ENOMEM;
+  p.xofs = (const int32_t*)t;
+  p.yofs = (const int32_t*)(t + (size_t)p.new_w * 4);
+  p.xalpha = (const int16_t*)(t + (size_t)p.new_w * 4 + (size_t)p.new_h * 4);
+  p.ybeta = (const int16_t*)(t + (size_t)p.new_w * 8 + (size_t)p.new_h * 4);
+  if (p.mode == 1) {
+    for (int i = 0; i < p.new_w; ++i) EIOKU_REQUIRE(xofs[i] >= 0 && xofs[i] < w, "xofs[%d]=%d outside the frame", i, xofs[i]);
+    EIOKU_HIP_CHECK(hipMemcpyAsync((void*)p.xofs, xofs, (size_t)p.new_w * 4, hipMemcpyHostToDevice, stream));
+    EIOKU_HIP_CHECK(hipMemcpyAsync((void*)p.yofs, yofs, (size_t)p.new_h * 4, hipMemcpyHostToDevice, stream));
+    EIOKU_HIP_CHECK(hipMemcpyAsync((void*)p.xalpha, xalpha, (size_t)p.new_w * 4, hipMemcpyHostToDevice, stream));
+    EIOKU_HIP_CHECK(hipMemcpyAsync((void*)p.ybeta, ybeta, (size_t)p.new_h * 4, hipMemcpyHostToDevice, stream));
+  }
+  return letterbox_forward(bgr_dev, n, p, (__half*)out_nhwc8_dev, stream);
+}
+
+int eioku_yolo_postprocess(const float* const* box_dev, const float* const* cls_dev, int n, const int* hl,
+                           const int* wl, int nc, float conf, float iou, int max_det, float gain, int pad_x,
+                           int pad_y, int src_w, int src_h, void* dets_dev, int32_t* counts_dev, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(box_dev && cls_dev && hl && wl && dets_dev && counts_dev, "NULL argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) return EIOKU_OK;
+  int A = 0;
+  for (int l = 0; l < 3; ++l) A += hl[l] * wl[l];
+  Cand* cands = (Cand*)scratch(kSlotWork1, (size_t)n * A * (sizeof(Cand) + 8));
+  int32_t* counts = (int32_t*)scratch(kSlotWork2, (size_t)n * 4);
+  if (!cands || !counts) return EIOKU_ENOMEM;
+  EIOKU_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)n * 4, stream));
+  const float* box[3] = {box_dev[0], box_dev[1], box_dev[2]};
+  const float* cls[3] = {cls_dev[0], cls_dev[1], cls_dev[2]};
+  int rc = decode_forward(box, cls, n, hl, wl, nc, conf, cands, counts, A, stream);
+  if (rc) return rc;
+  ScaleParams sp{gain, (float)pad_x, (float)pad_y, (float)src_w, (float)src_h};
+  return nms_forward(cands, counts, n, A, iou, max_det, 7680.0f, sp, (Det*)dets_dev, counts_dev, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// K3 / K5 / K6 / K7: the non-GEMM kernels of the detection stage.
+#pragma once
+
+#include "conv.h"
+
+namespace eioku {
+
+// One detection in ORIGINAL image pixels (after scale_boxes + clip), plus provenance for parity.
+struct Det {
+  float x1, y1, x2, y2;
+  float conf;
+  int32_t cls;
+  int32_t anchor;  // index into the concatenated anchor list (P3 | P4 | P5), row-major per level
+  int32_t pad;
+};
+static_assert(sizeof(Det) == 32, "Det layout is part of the C ABI");
+
+// Pre-NMS candidate in letterboxed-image pixels.
+struct Cand {
+  float x1, y1, x2, y2;
+  float conf;
+  int32_t cls;
+  int32_t anchor;
+  int32_t pad;
+};
+
+// K3. uint8 BGR (n,h,w,3) -> fp16 NHWC8 (n,H2,W2,8): cv2.resize INTER_LINEAR (fixed point 11 bit) or
+// the 2x2 area fast path, 114 padding, BGR->RGB, /255, channels 3..7 zero.
+//   xofs/yofs : source column/row of the first tap per destination column/row   (int32, new_w / new_h)
+//   xa/ya     : first-tap fixed-point weight (second = 2048 - first handled as separate table)
+struct LetterboxPlan {
+  int src_h, src_w;        // original frame
+  int new_h, new_w;        // resized (unpadded) size
+  int top, left;           // padding offsets
+  int out_h, out_w;        // letterboxed size (multiple of 32 for rect mode)
+  int mode;                // 0 = copy (no resize), 1 = bilinear fixed point, 2 = 2x2 area
+  const int32_t* xofs;     // [new_w]  (device)
+  const int32_t* yofs;     // [new_h]
+  const int16_t* xalpha;   // [new_w][2]
+  const int16_t* ybeta;    // [new_h][2]
+};
+int letterbox_forward(const uint8_t* bgr, int n, const LetterboxPlan& p, __half* out_nhwc8, hipStream_t stream);
+
+// K5. 5x5 stride-1 max pool (pad 2, -inf) on a channel slice -> another slice (SPPF chain).
+int maxpool5_forward(Slice in, Slice out, int N, int H, int W, int C, hipStream_t stream);
+// K5. nearest 2x upsample of a slice into a slice of a (2H,2W) buffer (fused concat write).
+int upsample2x_forward(Slice in, Slice out, int N, int H, int W, int C, hipStream_t stream);
+
+// K6. DFL decode + class max + confidence filter -> compacted per-image candidate lists.
+//   box[l]: fp32 [N,Hl,Wl,64], cls[l]: fp32 [N,Hl,Wl,nc]; strides 8/16/32.
+//   cands: [N][max_cand], counts: [N] (must be zeroed by the caller).
+int decode_forward(const float* const box[3], const float* const cls[3], int N, const int Hl[3],
+                   const int Wl[3], int nc, float conf_thres, Cand* cands, int32_t* counts,
+                   int max_cand, hipStream_t stream);
+
+// K7. per-image: sort by (conf desc, anchor asc), class-aware greedy NMS (IoU > thr suppresses),
+// keep <= max_det, then scale_boxes to the original frame and clip.
+struct ScaleParams {
+  float gain;        // (float)min(out_h/src_h, out_w/src_w)
+  float pad_x, pad_y;
+  float src_w, src_h;
+};
+int nms_forward(const Cand* cands, const int32_t* counts, int N, int max_cand, float iou_thres,
+                int max_det, float max_wh, ScaleParams sp, Det* dets, int32_t* det_counts,
+                hipStream_t stream);
+
+}  // namespace eioku

@@ -1,0 +1,407 @@
+// K3 letterbox, K5 maxpool/upsample glue, K6 DFL decode, K7 wavefront NMS.
+//
+// These are the exactness-critical, non-GEMM pieces of the detection stage: integer fixed-point
+// resize (OpenCV INTER_LINEAR semantics), fp32 box decode in the Ultralytics operation order, and
+// class-aware greedy NMS with the torchvision IoU expression, compiled with -ffp-contract=off so no
+// multiply-add is fused that the CPU reference does not fuse.
+#include "yolo_ops.h"
+
+namespace eioku {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// K3 letterbox + normalise
+// ---------------------------------------------------------------------------------------------
+struct LbArgs {
+  const uint8_t* bgr;
+  __half* out;
+  int n, src_h, src_w, new_h, new_w, top, left, out_h, out_w, mode;
+  const int32_t* xofs;
+  const int32_t* yofs;
+  const int16_t* xalpha;
+  const int16_t* ybeta;
+};
+
+__global__ __launch_bounds__(256) void k_letterbox(LbArgs a) {
+  const long long total = (long long)a.n * a.out_h * a.out_w;
+  long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total) return;
+  const int ox = (int)(i % a.out_w);
+  const long long t = i / a.out_w;
+  const int oy = (int)(t % a.out_h);
+  const int n = (int)(t / a.out_h);
+  const int y = oy - a.top, x = ox - a.left;
+  int v[3] = {114, 114, 114};
+  if (y >= 0 && y < a.new_h && x >= 0 && x < a.new_w) {
+    const uint8_t* img = a.bgr + (size_t)n * a.src_h * a.src_w * 3;
+    if (a.mode == 0) {
+      const uint8_t* p = img + ((size_t)y * a.src_w + x) * 3;
+      v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+    } else if (a.mode == 2) {  // INTER_LINEAR at exactly 1/2 scale takes OpenCV's 2x2 area path
+      const uint8_t* p0 = img + ((size_t)(2 * y) * a.src_w + 2 * x) * 3;
+      const uint8_t* p1 = p0 + (size_t)a.src_w * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = (p0[c] + p0[c + 3] + p1[c] + p1[c + 3] + 2) >> 2;
+    } else {
+      const int sy = a.yofs[y];
+      const int r0 = min(max(sy, 0), a.src_h - 1), r1 = min(max(sy + 1, 0), a.src_h - 1);
+      const int b0 = a.ybeta[2 * y], b1 = a.ybeta[2 * y + 1];
+      const int sx = a.xofs[x];
+      const int sx1 = min(sx + 1, a.src_w - 1);
+      const int a0 = a.xalpha[2 * x], a1 = a.xalpha[2 * x + 1];
+      const uint8_t* q0 = img + (size_t)r0 * a.src_w * 3;
+      const uint8_t* q1 = img + (size_t)r1 * a.src_w * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int h0 = q0[sx * 3 + c] * a0 + q0[sx1 * 3 + c] * a1;  // HResizeLinear, 11-bit weights
+        const int h1 = q1[sx * 3 + c] * a0 + q1[sx1 * 3 + c] * a1;
+        v[c] = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;  // VResizeLinear 8u
+      }
+    }
+  }
+  __half o[8];
+  o[0] = __float2half_rn((float)v[2] / 255.0f);  // BGR -> RGB
+  o[1] = __float2half_rn((float)v[1] / 255.0f);
+  o[2] = __float2half_rn((float)v[0] / 255.0f);
+#pragma unroll
+  for (int c = 3; c < 8; ++c) o[c] = __float2half_rn(0.f);
+  *reinterpret_cast<uint4*>(a.out + (size_t)i * 8) = *reinterpret_cast<uint4*>(o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 glue
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_maxpool5(const __half* in, int in_cs, __half* out, int out_cs,
+                                                  int N, int H, int W, int C8) {
+  const long long total = (long long)N * H * W * C8;
+  long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total) return;
+  const int u = (int)(i % C8);
+  long long t = i / C8;
+  const int x = (int)(t % W);
+  t /= W;
+  const int y = (int)(t % H);
+  const int n = (int)(t / H);
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  const _Float16 ninf = -__builtin_inff16();
+  half8 m = {ninf, ninf, ninf, ninf, ninf, ninf, ninf, ninf};
+  for (int dy = -2; dy <= 2; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= H) continue;
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int xx = x + dx;
+      if (xx < 0 || xx >= W) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(in + (((size_t)n * H + yy) * W + xx) * in_cs + u * 8);
+      m = __builtin_elementwise_max(m, *reinterpret_cast<const half8*>(&v));
+    }
+  }
+  *reinterpret_cast<uint4*>(out + (((size_t)n * H + y) * W + x) * out_cs + u * 8) = *reinterpret_cast<uint4*>(&m);
+}
+
+__global__ __launch_bounds__(256) void k_upsample2x(const __half* in, int in_cs, __half* out, int out_cs,
+                                                    int N, int H, int W, int C8) {
+  const long long total = (long long)N * H * W * C8;
+  long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total) return;
+  const int u = (int)(i % C8);
+  long long t = i / C8;
+  const int x = (int)(t % W);
+  t /= W;
+  const int y = (int)(t % H);
+  const int n = (int)(t / H);
+  const uint4 v = *reinterpret_cast<const uint4*>(in + (((size_t)n * H + y) * W + x) * in_cs + u * 8);
+  const int W2 = 2 * W, H2 = 2 * H;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+      *reinterpret_cast<uint4*>(out + (((size_t)n * H2 + 2 * y + dy) * W2 + 2 * x + dx) * out_cs + u * 8) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 decode: DFL(softmax 16 . arange) -> ltrb -> xywh*stride -> xyxy ; class max + conf filter
+// ---------------------------------------------------------------------------------------------
+struct DecArgs {
+  const float* box[3];
+  const float* cls[3];
+  int H[3], W[3], A0[3];  // A0 = anchor index base of the level
+  int N, nc, A;
+  float conf;
+  Cand* cands;      // dense [N][A]
+  unsigned long long* keys;  // compact [N][A]
+  int32_t* counts;
+};
+
+__device__ __forceinline__ float dfl_side(const float* __restrict__ l) {
+  float m = l[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) m = fmaxf(m, l[i]);
+  float e[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    e[i] = expf(l[i] - m);
+    s = s + e[i];
+  }
+  float d = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d = d + (e[i] / s) * (float)i;
+  return d;
+}
+
+__global__ __launch_bounds__(256) void k_decode(DecArgs a) {
+  const long long total = (long long)a.N * a.A;
+  long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i / a.A);
+  const int an = (int)(i % a.A);
+  const int lvl = an >= a.A0[2] ? 2 : (an >= a.A0[1] ? 1 : 0);
+  const int loc = an - a.A0[lvl];
+  const int W = a.W[lvl], H = a.H[lvl];
+  const size_t pix = (size_t)n * H * W + loc;
+  // class max first: most anchors stop here
+  const float* cl = a.cls[lvl] + pix * a.nc;
+  float best = cl[0];
+  int bj = 0;
+  for (int j = 1; j < a.nc; ++j) {
+    const float v = cl[j];
+    if (v > best) {  // first maximum wins, as torch.max does
+      best = v;
+      bj = j;
+    }
+  }
+  const float conf = 1.0f / (1.0f + expf(-best));
+  if (!(conf > a.conf)) return;
+  const float* bl = a.box[lvl] + pix * 64;
+  float side[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float l[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(bl + s * 16 + q * 4);
+      l[q * 4] = v.x; l[q * 4 + 1] = v.y; l[q * 4 + 2] = v.z; l[q * 4 + 3] = v.w;
+    }
+    side[s] = dfl_side(l);
+  }
+  const float stride = (float)(8 << lvl);
+  const float ax = (float)(loc % W) + 0.5f, ay = (float)(loc / W) + 0.5f;
+  // dist2bbox(xywh=True): x1y1 = anchor - lt ; x2y2 = anchor + rb ; c = (x1y1+x2y2)/2 ; wh = x2y2-x1y1
+  const float bx1 = ax - side[0], by1 = ay - side[1], bx2 = ax + side[2], by2 = ay + side[3];
+  const float cx = ((bx1 + bx2) / 2.0f) * stride, cy = ((by1 + by2) / 2.0f) * stride;
+  const float w = (bx2 - bx1) * stride, h = (by2 - by1) * stride;
+  // xywh2xyxy inside non_max_suppression
+  const float hw = w / 2.0f, hh = h / 2.0f;
+  Cand c;
+  c.x1 = cx - hw; c.y1 = cy - hh; c.x2 = cx + hw; c.y2 = cy + hh;
+  c.conf = conf; c.cls = bj; c.anchor = an; c.pad = 0;
+  a.cands[(size_t)n * a.A + an] = c;
+  const int pos = atomicAdd(&a.counts[n], 1);
+  a.keys[(size_t)n * a.A + pos] =
+      ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)an);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7 NMS: one workgroup per image.  LDS bitonic sort of (conf, anchor) keys, then wave 0 runs the
+// greedy pass 64 candidates at a time: every lane tests its box against the kept list, the chunk is
+// resolved in score order with ballots.
+// ---------------------------------------------------------------------------------------------
+struct NmsArgs {
+  const Cand* cands;
+  const unsigned long long* keys;
+  const int32_t* counts;
+  int A, max_det;
+  float iou, max_wh;
+  ScaleParams sp;
+  Det* dets;
+  int32_t* det_counts;
+};
+
+__device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1,
+                                       float by1, float bx2, float by2, float barea, float thr) {
+  const float xx1 = fmaxf(ax1, bx1), yy1 = fmaxf(ay1, by1);
+  const float xx2 = fminf(ax2, bx2), yy2 = fminf(ay2, by2);
+  const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+  const float inter = w * h;
+  const float ovr = inter / (aarea + barea - inter);
+  return ovr > thr;
+}
+
+__global__ __launch_bounds__(256) void k_nms(NmsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int C = min(a.counts[n], a.A);
+  int P = 1;
+  while (P < C) P <<= 1;
+  for (int i = tid; i < P; i += 256) key[i] = i < C ? a.keys[(size_t)n * a.A + i] : 0ull;
+  __syncthreads();
+  // descending bitonic sort
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long x = key[i], y = key[l];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) {
+            key[i] = y;
+            key[l] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid >= 64) return;
+  // kept list lives after the keys (P*8 bytes, 16-aligned): 5 floats per box
+  float* kb = reinterpret_cast<float*>(smem + (size_t)(P > 0 ? P : 1) * 8);
+  int* kanchor = reinterpret_cast<int*>(kb + 5 * a.max_det);
+  const int lane = tid;
+  const Cand* cd = a.cands + (size_t)n * a.A;
+  int kept = 0;
+  for (int base = 0; base < C && kept < a.max_det; base += 64) {
+    const int i = base + lane;
+    const bool valid = i < C;
+    float x1 = 0, y1 = 0, x2 = 0, y2 = 0, area = 0;
+    int an = 0;
+    if (valid) {
+      an = (int)(0xFFFFFFFFu - (unsigned)(key[i] & 0xFFFFFFFFull));
+      const Cand c = cd[an];
+      const float off = (float)c.cls * a.max_wh;  // class-aware: boxes + cls * max_wh
+      x1 = c.x1 + off; y1 = c.y1 + off; x2 = c.x2 + off; y2 = c.y2 + off;
+      area = (x2 - x1) * (y2 - y1);
+    }
+    bool alive = valid;
+    for (int k = 0; k < kept; ++k) {
+      const float* q = kb + 5 * k;
+      if (alive && iou_gt(q[0], q[1], q[2], q[3], q[4], x1, y1, x2, y2, area, a.iou)) alive = false;
+    }
+    unsigned long long mask = __ballot(alive);
+    while (mask != 0 && kept < a.max_det) {
+      const int l = __ffsll((long long)mask) - 1;  // best surviving score in the chunk
+      const float lx1 = __shfl(x1, l, 64), ly1 = __shfl(y1, l, 64), lx2 = __shfl(x2, l, 64),
+                  ly2 = __shfl(y2, l, 64), la = __shfl(area, l, 64);
+      const int lan = __shfl(an, l, 64);
+      if (lane == 0) {
+        float* q = kb + 5 * kept;
+        q[0] = lx1; q[1] = ly1; q[2] = lx2; q[3] = ly2; q[4] = la;
+        kanchor[kept] = lan;
+      }
+      kept++;
+      if (lane == l) alive = false;
+      if (alive && lane > l && iou_gt(lx1, ly1, lx2, ly2, la, x1, y1, x2, y2, area, a.iou)) alive = false;
+      mask = __ballot(alive) & ~((2ull << l) - 1ull);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);  // lane 0's LDS writes are visible to the wave below
+  // emit: original (un-offset) boxes -> scale_boxes -> clip
+  for (int k = lane; k < kept; k += 64) {
+    const Cand c = cd[kanchor[k]];
+    Det d;
+    d.x1 = fminf(fmaxf((c.x1 - a.sp.pad_x) / a.sp.gain, 0.f), a.sp.src_w);
+    d.y1 = fminf(fmaxf((c.y1 - a.sp.pad_y) / a.sp.gain, 0.f), a.sp.src_h);
+    d.x2 = fminf(fmaxf((c.x2 - a.sp.pad_x) / a.sp.gain, 0.f), a.sp.src_w);
+    d.y2 = fminf(fmaxf((c.y2 - a.sp.pad_y) / a.sp.gain, 0.f), a.sp.src_h);
+    d.conf = c.conf;
+    d.cls = c.cls;
+    d.anchor = c.anchor;
+    d.pad = 0;
+    a.dets[(size_t)n * a.max_det + k] = d;
+  }
+  if (lane == 0) a.det_counts[n] = kept;
+}
+
+inline unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+int letterbox_forward(const uint8_t* bgr, int n, const LetterboxPlan& p, __half* out, hipStream_t stream) {
+  if (n == 0) return EIOKU_OK;
+  LbArgs a{bgr, out, n, p.src_h, p.src_w, p.new_h, p.new_w, p.top, p.left, p.out_h, p.out_w, p.mode,
+           p.xofs, p.yofs, p.xalpha, p.ybeta};
+  hipLaunchKernelGGL(k_letterbox, dim3(blocks_for((long long)n * p.out_h * p.out_w)), dim3(256), 0, stream, a);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+int maxpool5_forward(Slice in, Slice out, int N, int H, int W, int C, hipStream_t stream) {
+  EIOKU_REQUIRE(C % 8 == 0 && in.cstride % 8 == 0 && in.coff % 8 == 0 && out.cstride % 8 == 0 && out.coff % 8 == 0,
+                "maxpool slices must be 8-channel aligned");
+  if (N == 0) return EIOKU_OK;
+  hipLaunchKernelGGL(k_maxpool5, dim3(blocks_for((long long)N * H * W * (C / 8))), dim3(256), 0, stream,
+                     in.ptr + in.coff, in.cstride, out.ptr + out.coff, out.cstride, N, H, W, C / 8);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+int upsample2x_forward(Slice in, Slice out, int N, int H, int W, int C, hipStream_t stream) {
+  EIOKU_REQUIRE(C % 8 == 0 && in.cstride % 8 == 0 && in.coff % 8 == 0 && out.cstride % 8 == 0 && out.coff % 8 == 0,
+                "upsample slices must be 8-channel aligned");
+  if (N == 0) return EIOKU_OK;
+  hipLaunchKernelGGL(k_upsample2x, dim3(blocks_for((long long)N * H * W * (C / 8))), dim3(256), 0, stream,
+                     in.ptr + in.coff, in.cstride, out.ptr + out.coff, out.cstride, N, H, W, C / 8);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+int decode_forward(const float* const box[3], const float* const cls[3], int N, const int Hl[3],
+                   const int Wl[3], int nc, float conf_thres, Cand* cands, int32_t* counts, int max_cand,
+                   hipStream_t stream) {
+  if (N == 0) return EIOKU_OK;
+  DecArgs a;
+  int A = 0;
+  for (int l = 0; l < 3; ++l) {
+    a.box[l] = box[l];
+    a.cls[l] = cls[l];
+    a.H[l] = Hl[l];
+    a.W[l] = Wl[l];
+    a.A0[l] = A;
+    A += Hl[l] * Wl[l];
+  }
+  EIOKU_REQUIRE(A == max_cand, "candidate capacity %d != anchors %d", max_cand, A);
+  a.N = N;
+  a.nc = nc;
+  a.A = A;
+  a.conf = conf_thres;
+  a.cands = cands;
+  // keys live right after the dense candidate array (see yolo.hip workspace layout)
+  a.keys = reinterpret_cast<unsigned long long*>(cands + (size_t)N * A);
+  a.counts = counts;
+  hipLaunchKernelGGL(k_decode, dim3(blocks_for((long long)N * A)), dim3(256), 0, stream, a);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+int nms_forward(const Cand* cands, const int32_t* counts, int N, int max_cand, float iou_thres, int max_det,
+                float max_wh, ScaleParams sp, Det* dets, int32_t* det_counts, hipStream_t stream) {
+  if (N == 0) return EIOKU_OK;
+  EIOKU_REQUIRE(max_cand <= 16384, "more than 16384 anchors per image (%d) is not supported by the LDS sort", max_cand);
+  EIOKU_REQUIRE(max_det > 0 && max_det <= 1024, "max_det %d out of range", max_det);
+  int P = 1;
+  while (P < max_cand) P <<= 1;
+  const size_t lds = (size_t)P * 8 + (size_t)max_det * 6 * 4;
+  static size_t lds_attr = 0;
+  if (lds > 64 * 1024 && lds > lds_attr) {
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nms),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_attr = lds;
+  }
+  NmsArgs a;
+  a.cands = cands;
+  a.keys = reinterpret_cast<const unsigned long long*>(cands + (size_t)N * max_cand);
+  a.counts = counts;
+  a.A = max_cand;
+  a.max_det = max_det;
+  a.iou = iou_thres;
+  a.max_wh = max_wh;
+  a.sp = sp;
+  a.dets = dets;
+  a.det_counts = det_counts;
+  hipLaunchKernelGGL(k_nms, dim3(N), dim3(256), lds, stream, a);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+}  // namespace eioku

@@ -125,6 +125,68 @@ int eioku_conv2d_f16(const void* in_nhwc, int n, int h, int w, int in_cstride, i
                      int act_silu, const void* residual, int res_cstride, int res_coff,
                      void* out_nhwc, int out_cstride, int out_coff, float* out_f32, void* stream);
 
+/* YOLOv8 detector handle.  Replaces `YOLO(model_path); model.to(device)` + `model(frame, conf=..)`
+ * of ModelManager.detect_objects / detect_faces (model_manager.py:252-254,270-275 / :346-348,
+ * :364-369).  The graph is the Ultralytics yolov8 layout parameterised by its backbone widths
+ * ch5 = {c1..c5} and C2f repeats depth4 (n: {16,32,64,128,256},{1,2,2,1}; s: {32,..,512},{1,2,2,1};
+ * m: {48,96,192,384,576},{2,4,4,2}); nc = 80 for COCO models, 1 for yolov8n-face.
+ * Weights are set per convolution (BatchNorm already folded: conv + bias), indexed in module order;
+ * eioku_yolo_conv_info returns the Ultralytics state-dict prefix ("model.2.m.0.cv1.conv", ...;
+ * the three Detect output convs are "model.22.cv2.<l>.2" / "model.22.cv3.<l>.2") and the shape.
+ * Convolution 0 takes 8 input channels: RGB in channels 0..2, channels 3..7 must be zero weights.
+ */
+typedef struct eioku_yolo eioku_yolo_t;
+int eioku_yolo_create(const int* ch5, const int* depth4, int nc, eioku_yolo_t** out);
+void eioku_yolo_destroy(eioku_yolo_t* y);
+int eioku_yolo_num_convs(const eioku_yolo_t* y);
+int eioku_yolo_conv_info(const eioku_yolo_t* y, int idx, char* name, size_t name_cap, int* cout, int* cin,
+                         int* ksize, int* stride);
+int eioku_yolo_set_conv(eioku_yolo_t* y, int idx, const float* weight_oihw, const float* bias);
+
+/* Raw network: fp16 NHWC8 input (device, n x h x w x 8, h,w % 32 == 0) -> the six Detect maps
+ * (device fp32): box_out[l] [n,h/s,w/s,64], cls_out[l] [n,h/s,w/s,nc], s = 8,16,32.  NULL entries
+ * are skipped.  Asynchronous on `stream`. */
+int eioku_yolo_forward(eioku_yolo_t* y, const void* in_nhwc8_f16, int n, int h, int w,
+                       float* const* box_out, float* const* cls_out, void* stream);
+/* Algorithmic conv FLOPs (2*Cout*Cin*k*k per output pixel, unpadded) of the last forward. */
+int eioku_yolo_last_conv_flops(const eioku_yolo_t* y, double* flops);
+
+/* One detection, ORIGINAL-frame pixels (after scale_boxes + clip), 32 bytes. */
+typedef struct {
+  float x1, y1, x2, y2;
+  float conf;
+  int32_t cls;
+  int32_t anchor; /* index into the concatenated P3|P4|P5 anchor list: the "post-NMS box index" */
+  int32_t pad;
+} eioku_det_t;
+
+/* Full per-frame pipeline on n BGR frames (u8, n x h x w x 3): K3 letterbox (cv2.resize
+ * INTER_LINEAR fixed point / 2x2 area / copy, 114 padding, RGB, /255) -> network -> K6 decode ->
+ * K7 class-aware NMS (IoU > iou suppresses, <= max_det kept, score order) -> scale_boxes + clip.
+ * The letterbox geometry and the resize coefficient tables are produced by the host in the
+ * reference's Python float semantics (eioku_amd/detect.py):
+ *   lb_geom[9] = {new_h, new_w, top, left, out_h, out_w, mode(0 copy,1 bilinear,2 area), pad_x, pad_y}
+ *   xofs[new_w], yofs[new_h] : first source column / row;  xalpha[new_w][2], ybeta[new_h][2] :
+ *   11-bit fixed point tap weights (HOST pointers; may be NULL unless mode == 1).
+ * dets_out: n x max_det eioku_det_t, counts_out: n int32 (host or device per `mem`; frames too).
+ */
+int eioku_yolo_detect(eioku_yolo_t* y, const uint8_t* bgr, int n, int h, int w, const int32_t* lb_geom,
+                      const int32_t* xofs, const int32_t* yofs, const int16_t* xalpha,
+                      const int16_t* ybeta, float gain, float conf, float iou, int max_det,
+                      void* dets_out, int32_t* counts_out, int mem, void* stream);
+
+/* Stage entry points (device pointers, asynchronous): K3 alone and K6+K7 alone.
+ * eioku_letterbox_f16: BGR u8 frames -> fp16 NHWC8 (n x out_h x out_w x 8) network input.
+ * eioku_yolo_postprocess: the six Detect maps -> detections, same semantics as eioku_yolo_detect
+ * (hl/wl: map sizes of P3,P4,P5; gain/pad/src: scale_boxes parameters). */
+int eioku_letterbox_f16(const uint8_t* bgr_dev, int n, int h, int w, const int32_t* lb_geom,
+                        const int32_t* xofs, const int32_t* yofs, const int16_t* xalpha,
+                        const int16_t* ybeta, void* out_nhwc8_dev, void* stream);
+int eioku_yolo_postprocess(const float* const* box_dev, const float* const* cls_dev, int n, const int* hl,
+                           const int* wl, int nc, float conf, float iou, int max_det, float gain,
+                           int pad_x, int pad_y, int src_w, int src_h, void* dets_dev,
+                           int32_t* counts_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
