@@ -3,8 +3,10 @@
 Bars (written here, as the tier asks):
   K3 letterbox            bit-exact (integer resize, one fp32 divide, one RNE to fp16)
   K4/K5 network           fp16 network vs the same fp16 network on torch-CPU: the fp32 accumulation
-                          order differs, every layer rounds to fp16 -> head logits agree to
-                          HEAD_ATOL + HEAD_RTOL*|ref| (max) and HEAD_MEAN (mean abs)
+                          order differs and every one of the ~25 layers on a path rounds to fp16
+                          (ulp 2**-11), so head logits drift by ~1e-3 of the map's RMS on average
+                          (measured 0.9-1.7e-3) and < 1.2e-2 at worst; bars: max <= HEAD_MAX*rms,
+                          mean <= HEAD_MEAN*rms
   K6+K7 decode + NMS      given IDENTICAL head maps: kept anchor indices, order and classes exact;
                           conf / box coordinates within BOX_RTOL (device expf vs numpy exp, ulps)
   end to end              same kept set whenever the oracle's own result is stable under a
@@ -18,7 +20,7 @@ from oracle import prng, yolo as oy
 
 pytestmark = pytest.mark.gpu
 
-HEAD_ATOL, HEAD_RTOL, HEAD_MEAN = 0.06, 0.03, 0.006
+HEAD_MAX, HEAD_MEAN = 0.025, 0.005
 BOX_RTOL = 2e-5
 
 
@@ -62,10 +64,10 @@ def _check_heads(got, want, tag):
     for g, r in zip(got, want):
         g = g.cpu().numpy()
         err = np.abs(g - r)
+        rms = float(np.sqrt((r.astype(np.float64) ** 2).mean()))
         assert g.shape == r.shape
-        assert err.max() <= HEAD_ATOL + HEAD_RTOL * np.abs(r).max(), (tag, float(err.max()))
-        assert np.all(err <= HEAD_ATOL + HEAD_RTOL * np.abs(r)), (tag, float(err.max()))
-        assert err.mean() <= HEAD_MEAN, (tag, float(err.mean()))
+        assert err.max() <= HEAD_MAX * rms, (tag, float(err.max()), rms)
+        assert err.mean() <= HEAD_MEAN * rms, (tag, float(err.mean()), rms)
 
 
 @pytest.mark.parametrize("variant,nc,n,h,w", [("n", 80, 2, 96, 160), ("n", 1, 1, 64, 96), ("s", 80, 1, 64, 64),
@@ -160,9 +162,28 @@ def test_nms_keeps_at_most_max_det_and_suppresses_duplicates(gpu):
 # ---------------------------------------------------------------------------------------------
 # end to end
 # ---------------------------------------------------------------------------------------------
+def _calibrated_state(frames, variant="n", nc=80, seed=7, frac=0.015):
+    """Random weights whose Detect logits are O(1) on THESE frames (a random net's logit scale depends
+    on its input): rescale the six output convs so box logits have std 2 and class logits std 3,
+    shifted so that about `frac` of the anchors pass conf 0.25 and none saturates."""
+    state = W.random_state(variant, nc, seed=seed)
+    box, cls = oy.Net(state, *W.YOLO_VARIANTS[variant], nc).forward(oy.preprocess(frames))
+    scaled = [(c - c.mean()) * (3.0 / c.std()) for c in cls]
+    top = np.concatenate([c.max(axis=-1).reshape(-1) for c in scaled])
+    shift = float(np.log(0.25 / 0.75) - np.quantile(top, 1.0 - frac))
+    for l in range(3):
+        w, b = state[f"model.22.cv2.{l}.2"]
+        state[f"model.22.cv2.{l}.2"] = ((w * (2.0 / box[l].std())).astype(np.float32), (b * 0).astype(np.float32))
+        w, b = state[f"model.22.cv3.{l}.2"]
+        sc = 3.0 / cls[l].std()
+        state[f"model.22.cv3.{l}.2"] = ((w * sc).astype(np.float32),
+                                        ((b - cls[l].mean()) * sc + shift).astype(np.float32))
+    return state
+
+
 def test_detect_end_to_end_vs_oracle(gpu):
     frames = prng.synth_frames_bgr(21, 2, 240, 427)
-    state = W.random_state("n", 80, seed=7)
+    state = _calibrated_state(frames)
     det = D.Yolov8Detector("n", 80, state)
     conf = 0.25
     dets, counts = det.detect(_dev(frames, gpu), conf=conf)
@@ -170,23 +191,30 @@ def test_detect_end_to_end_vs_oracle(gpu):
     assert np.array_equal(counts, counts_h) and np.array_equal(dets, dets_h)
     net = oy.Net(state, *W.YOLO_VARIANTS["n"], 80)
     ref, (_, _, boxes, scores) = oy.detect(net, frames, conf)
-    # network drift (HEAD_ATOL) moves scores by ~1e-2 and boxes by a fraction of a pixel: the kept
-    # set must agree wherever the oracle's decision has more margin than that
+    # Network drift (HEAD_MAX) moves scores by ~1e-2 and boxes by a fraction of a pixel.  On smooth
+    # frames neighbouring anchors carry near-identical boxes and scores, so WHICH of them wins NMS
+    # is ill-conditioned; the detection it stands for is not.  Bar: every oracle detection with more
+    # conf margin than the drift has a HIP detection of the same class with IoU >= 0.85 and conf
+    # within 0.03, and vice versa, for at least 80 % of them (NMS chains near IoU 0.7 flip too).  (Exact index parity is asserted on identical head maps above.)
+    def iou(a, b):
+        iw = max(0.0, min(a[2], b[2]) - max(a[0], b[0]))
+        ih = max(0.0, min(a[3], b[3]) - max(a[1], b[1]))
+        u = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - iw * ih
+        return iw * ih / u if u > 0 else 0.0
+
     for i in range(2):
-        got = set(int(a) for a in dets["anchor"][i, :counts[i]])
-        want = set(d["anchor"] for d in ref[i])
-        sure = set(d["anchor"] for d in ref[i] if d["conf"] > conf + 0.03)
-        assert len(sure - got) <= max(1, len(sure) // 10), (len(sure), len(sure - got))
-        both = got & want
-        assert len(both) >= 0.8 * max(len(want), 1)
-        rd = {d["anchor"]: d for d in ref[i]}
-        for k in range(counts[i]):
-            a = int(dets["anchor"][i, k])
-            if a in rd:
-                gb = np.array([dets[f][i, k] for f in ("x1", "y1", "x2", "y2")])
-                assert np.abs(gb - rd[a]["xyxy"]).max() < 2.0  # pixels in the 427x240 frame
-                assert abs(float(dets["conf"][i, k]) - rd[a]["conf"]) < 0.03
-                assert int(dets["cls"][i, k]) == rd[a]["cls"] or rd[a]["conf"] < conf + 0.03
+        got = [(np.array([dets[f][i, k] for f in ("x1", "y1", "x2", "y2")], dtype=np.float64),
+                float(dets["conf"][i, k]), int(dets["cls"][i, k])) for k in range(counts[i])]
+        want = [(d["xyxy"].astype(np.float64), d["conf"], d["cls"]) for d in ref[i]]
+        assert len(want) >= 5, "calibration should leave the oracle some detections"
+
+        def matched(x, pool):
+            return any(c == x[2] and iou(x[0], b) >= 0.85 and abs(s - x[1]) < 0.03 for b, s, c in pool)
+
+        sure_w = [x for x in want if x[1] > conf + 0.03]
+        sure_g = [x for x in got if x[1] > conf + 0.03]
+        assert sum(matched(x, got) for x in sure_w) >= 0.8 * len(sure_w), (len(sure_w), len(got))
+        assert sum(matched(x, want) for x in sure_g) >= 0.8 * len(sure_g), (len(sure_g), len(want))
     det.close()
 
 
