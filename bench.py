@@ -25,6 +25,7 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
+MFMA_F32_PEAK_TFLOPS = 157.3
 
 
 def parse_args():
@@ -35,73 +36,97 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (BASELINE cfg2: 64)")
     ap.add_argument("--height", type=int, default=640)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--model", default="yolov8n.pt")
+    ap.add_argument("--conf", type=float, default=0.25)
+    ap.add_argument("--stages", default="scene,detect,embed", help="comma list (debug); default = all built stages")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU oracle sample budget")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU oracle sample budget")
     return ap.parse_args()
 
 
-class ScenePipeline:
-    """Stages built so far.  Each step consumes `batch` BGR frames already resident in HBM."""
+class Pipeline:
+    """Each step consumes `batch` BGR frames already resident in HBM and leaves its results in HBM."""
+
+    BUILT = ("scene", "detect")  # stages that exist as HIP kernels; "embed" joins when K8 lands
 
     def __init__(self, args, device, rank):
-        from eioku_amd import synth
+        from eioku_amd import detect, synth
 
         self.args = args
         self.device = device
-        self.batch = args.batch
-        self.h, self.w = args.height, args.width
-        # two alternating batches of one synthetic video (scene changes included), carried prev frame
+        self.batch, self.h, self.w = args.batch, args.height, args.width
+        want = [s for s in args.stages.split(",") if s]
+        self.stages = [s for s in want if s in self.BUILT]
+        self.missing = [s for s in ("scene", "detect", "embed") if s not in self.stages]
+        # two alternating batches of one synthetic video (scene changes included)
         self.frames = [synth.frames_bgr(1234 + rank, self.batch, self.h, self.w, device, first_frame=b * self.batch)
                        for b in range(2)]
+        self.luma = [f[..., 1].contiguous() for f in self.frames]  # stands in for the decoder's Y plane
         self.prev = None
+        self.det = None
+        if "detect" in self.stages:
+            self.det = detect.Yolov8Detector.from_model_name(args.model, seed=7)  # random-init weights, exact shapes
+            # a random net's logit scale is arbitrary: give it a trained detector's candidate density
+            self.det.calibrate_random_head(self.frames[0][:8], frac=0.01, conf=args.conf)
         self.last = None
-
-    stages = ["scene(ContentDetector HSV K2 + luma SAD K1)"]
-    missing = ["detect(YOLOv8n)", "embed(MiniLM)"]
 
     def step(self, i):
         from eioku_amd import scene
 
         f = self.frames[i & 1]
-        sums = scene.hsv_sums(f, self.prev, keep_on_device=True)
-        sad = scene.luma_sad(self._luma(i), keep_on_device=True)
-        self.prev = f[-1]
-        self.last = (sums, sad)
-
-    def _luma(self, i):
-        # synthetic Y plane: the decoder would hand this over; here = G channel copy made at init
-        if not hasattr(self, "_y"):
-            self._y = [fr[..., 1].contiguous() for fr in self.frames]
-        return self._y[i & 1]
+        out = []
+        if "scene" in self.stages:
+            out.append(scene.hsv_sums(f, self.prev, keep_on_device=True))
+            out.append(scene.luma_sad(self.luma[i & 1], keep_on_device=True))
+            self.prev = f[-1]
+        if self.det is not None:
+            out.append(self.det.detect(f, conf=self.args.conf, keep_on_device=True))
+        self.last = out
 
     def dominant(self):
         from eioku_amd import _lib
 
+        if self.det is not None:
+            ms, cnt = _lib.prof_read(_lib.PROF_CONV)
+            flops_step = self.det.last_conv_flops()  # algorithmic 2*Cout*Cin*k*k per output pixel, whole batch
+            return {"kernel": "k_conv_igemm (all YOLOv8 conv launches of a step)", "bound": "mfma", "unit": "TFLOP/s",
+                    "peak": MFMA_F16_PEAK_TFLOPS, "alg_total": flops_step * self.args.steps, "scale": 1e12,
+                    "ms_total": ms, "launches": cnt, "alg_per_step": flops_step}
         ms, cnt = _lib.prof_read(_lib.PROF_SCENE_HSV)
-        alg_bytes = 3.0 * self.h * self.w * self.batch  # SURVEY 8d: 3*W*H bytes per frame
+        alg = 3.0 * self.h * self.w * self.batch  # SURVEY 8d: 3*W*H bytes per frame
         return {"kernel": "k_hsv_sums", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                "alg_per_launch": alg_bytes, "ms_total": ms, "launches": cnt}
+                "alg_total": alg * cnt, "scale": 1e9, "ms_total": ms, "launches": cnt, "alg_per_step": alg}
 
 
-def cpu_baseline_scene(args):
-    """CPU oracle (numpy port) on a bounded sample of the same workload: frames/s on host cores."""
+def cpu_baseline(args, stages):
+    """CPU oracle (numpy / torch-CPU port) on a bounded sample of the same workload: frames/s."""
     import numpy as np
-    from oracle import prng, scene as oscene
+    import torch
 
-    n = 3
+    from eioku_amd import weights as W
+    from oracle import prng, scene as oscene, yolo as oy
+
+    n = 2
     frames = prng.synth_frames_bgr(1234, n, args.height, args.width)
+    net = None
+    if "detect" in stages:
+        variant, nc, _ = W.variant_from_model_name(args.model)
+        net = oy.Net(W.random_state(variant, nc, 7), *W.YOLO_VARIANTS[variant], nc)
     t0 = time.perf_counter()
     done = 0
     while True:
-        oscene.content_sums(frames)
-        oscene.luma_sad(np.ascontiguousarray(frames[..., 1]))
-        done += n - 1  # n frames give n-1 scored transitions
-        if time.perf_counter() - t0 > args.cpu_seconds / 3:
+        if "scene" in stages:
+            oscene.content_sums(frames)
+            oscene.luma_sad(np.ascontiguousarray(frames[..., 1]))
+        if net is not None:
+            oy.detect(net, frames, args.conf)
+        done += n
+        if time.perf_counter() - t0 > args.cpu_seconds:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"oracle scene stage (HSV + luma SAD) on {n} synthetic {args.height}x{args.width} frames, "
-                      f"{done} frame transitions in {dt:.1f}s, numpy single thread"}
+    return {"value": done / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle stages {'+'.join(stages)} on {n} synthetic {args.height}x{args.width} frames per pass, "
+                      f"{done} frames in {dt:.1f}s; numpy (1 thread) + torch-CPU ({torch.get_num_threads()} threads)"}
 
 
 def main():
@@ -125,7 +150,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
-    pipe = ScenePipeline(args, device, rank)
+    pipe = Pipeline(args, device, rank)
 
     def barrier():
         if world > 1:
@@ -150,8 +175,9 @@ def main():
 
     dom = pipe.dominant()
     avg_ms = dom["ms_total"] / max(dom["launches"], 1)
-    achieved = dom["alg_per_launch"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    achieved = dom["alg_total"] / (dom["ms_total"] * 1e-3) / dom["scale"] if dom["ms_total"] > 0 else 0.0
     frames_total = args.batch * args.steps * world
+    note = "" if not pipe.missing else f"; NOT YET BUILT (value is not the full metric): {', '.join(pipe.missing)}"
     out = {
         "metric": "frames/sec (scene+detect+embed) per node",
         "value": frames_total / elapsed,
@@ -163,19 +189,18 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u8",
+        "dtype": "f16" if pipe.det is not None else "u8",
         "data": "synthetic",
-        "config": {"workload": f"{args.batch}x{args.height}x{args.width} BGR u8 frames/step/GPU resident in HBM; "
-                               f"stages run: {', '.join(pipe.stages)}; NOT YET BUILT (so value is not the full metric): "
-                               f"{', '.join(pipe.missing)}",
+        "config": {"workload": f"{args.batch}x{args.height}x{args.width} BGR u8 frames/step/GPU resident in HBM, "
+                               f"{args.model} random-init; stages run: {', '.join(pipe.stages)}{note}",
                    "batch": args.batch, "frame": [args.height, args.width], "parallelism": f"shard-by-video x{world}"},
         "roofline": {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": achieved, "peak": dom["peak"],
                      "unit": dom["unit"], "frac": achieved / dom["peak"], "traffic": None,
-                     "avg_kernel_ms": avg_ms, "launches": dom["launches"],
-                     "algorithmic_per_launch": dom["alg_per_launch"]},
+                     "avg_kernel_ms": avg_ms, "launches": dom["launches"], "kernel_ms_per_step": dom["ms_total"] / args.steps,
+                     "algorithmic_per_step": dom["alg_per_step"]},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_scene(args)
+        out["cpu_baseline"] = cpu_baseline(args, pipe.stages)
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -150,27 +150,45 @@ __device__ __forceinline__ float dfl_side(const float* __restrict__ l) {
   return d;
 }
 
+// 16 lanes per anchor: the class row is read with coalesced float4 loads and reduced with shuffles
+// (first maximum wins, as torch.max does); lane 0 of the group decodes the box of the few anchors
+// that pass the confidence filter, in the reference's sequential fp32 order.
 __global__ __launch_bounds__(256) void k_decode(DecArgs a) {
   const long long total = (long long)a.N * a.A;
-  long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= total) return;
+  const long long gid = blockIdx.x * 256ll + threadIdx.x;
+  const long long i = gid >> 4;
+  const int sub = (int)(gid & 15);
+  if (i >= total) return;  // uniform per 16-lane group; shuffles below stay inside the group
   const int n = (int)(i / a.A);
   const int an = (int)(i % a.A);
   const int lvl = an >= a.A0[2] ? 2 : (an >= a.A0[1] ? 1 : 0);
   const int loc = an - a.A0[lvl];
   const int W = a.W[lvl], H = a.H[lvl];
   const size_t pix = (size_t)n * H * W + loc;
-  // class max first: most anchors stop here
   const float* cl = a.cls[lvl] + pix * a.nc;
-  float best = cl[0];
-  int bj = 0;
-  for (int j = 1; j < a.nc; ++j) {
-    const float v = cl[j];
-    if (v > best) {  // first maximum wins, as torch.max does
-      best = v;
-      bj = j;
+  float best = -INFINITY;
+  int bj = 0x7FFFFFFF;
+  if ((a.nc & 3) == 0) {
+    for (int c = sub * 4; c < a.nc; c += 64) {
+      const float4 v = *reinterpret_cast<const float4*>(cl + c);
+      if (v.x > best) { best = v.x; bj = c; }
+      if (v.y > best) { best = v.y; bj = c + 1; }
+      if (v.z > best) { best = v.z; bj = c + 2; }
+      if (v.w > best) { best = v.w; bj = c + 3; }
+    }
+  } else {
+    for (int c = sub; c < a.nc; c += 16) {
+      const float v = cl[c];
+      if (v > best) { best = v; bj = c; }
     }
   }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off, 16);
+    const int oj = __shfl_xor(bj, off, 16);
+    if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+  }
+  if (sub != 0) return;
   const float conf = 1.0f / (1.0f + expf(-best));
   if (!(conf > a.conf)) return;
   const float* bl = a.box[lvl] + pix * 64;
@@ -369,7 +387,7 @@ int decode_forward(const float* const box[3], const float* const cls[3], int N, 
   // keys live right after the dense candidate array (see yolo.hip workspace layout)
   a.keys = reinterpret_cast<unsigned long long*>(cands + (size_t)N * A);
   a.counts = counts;
-  hipLaunchKernelGGL(k_decode, dim3(blocks_for((long long)N * A)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_decode, dim3(blocks_for((long long)N * A * 16)), dim3(256), 0, stream, a);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }

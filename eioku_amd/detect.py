@@ -147,6 +147,7 @@ class Yolov8Detector:
         return out
 
     def load_state(self, state: dict) -> None:
+        self._state = dict(state)
         for i, (name, cout, cin, k, _) in enumerate(self._table):
             w, b = state[name]
             w = np.asarray(w, dtype=np.float32)
@@ -190,6 +191,26 @@ class Yolov8Detector:
         f = C.c_double(0)
         _lib.check(self._lib.eioku_yolo_last_conv_flops(self._h, C.byref(f)), "eioku_yolo_last_conv_flops")
         return f.value
+
+    def calibrate_random_head(self, frames_bgr, frac: float = 0.01, conf: float = 0.25):
+        """Random-init models only (bench): rescale the six Detect output convs so that, on these
+        frames, box logits have std 2 and class logits std 3 with about ``frac`` of the anchors above
+        ``conf`` - the candidate density of a trained detector, which sets the decode/NMS workload."""
+        import torch
+
+        x, _ = letterbox_f16(frames_bgr)
+        box, cls = self.forward_raw(x)
+        scaled = [(c - c.mean()) * (3.0 / c.std()) for c in cls]
+        top = torch.cat([c.amax(dim=-1).reshape(-1) for c in scaled])
+        shift = float(math.log(conf / (1 - conf)) - torch.quantile(top[:: max(1, top.numel() // 1_000_000)].float(), 1.0 - frac))
+        for l in range(3):
+            w, b = self._state[f"model.22.cv2.{l}.2"]
+            self._state[f"model.22.cv2.{l}.2"] = ((w * (2.0 / float(box[l].std()))).astype(np.float32), b * 0)
+            w, b = self._state[f"model.22.cv3.{l}.2"]
+            sc = 3.0 / float(cls[l].std())
+            self._state[f"model.22.cv3.{l}.2"] = ((w * sc).astype(np.float32),
+                                                  ((b - float(cls[l].mean())) * sc + shift).astype(np.float32))
+        self.load_state(self._state)
 
     # ---- frames -> detections ------------------------------------------------------------------
     def detect(self, frames_bgr, conf: float = 0.25, iou: float = 0.7, max_det: int = 300, imgsz: int = 640,

@@ -194,7 +194,7 @@ def test_detect_end_to_end_vs_oracle(gpu):
     # Network drift (HEAD_MAX) moves scores by ~1e-2 and boxes by a fraction of a pixel.  On smooth
     # frames neighbouring anchors carry near-identical boxes and scores, so WHICH of them wins NMS
     # is ill-conditioned; the detection it stands for is not.  Bar: every oracle detection with more
-    # conf margin than the drift has a HIP detection of the same class with IoU >= 0.85 and conf
+    # conf margin than the drift has a HIP detection of the same class with IoU >= 0.7 (the NMS radius) and conf
     # within 0.03, and vice versa, for at least 80 % of them (NMS chains near IoU 0.7 flip too).  (Exact index parity is asserted on identical head maps above.)
     def iou(a, b):
         iw = max(0.0, min(a[2], b[2]) - max(a[0], b[0]))
@@ -209,7 +209,7 @@ def test_detect_end_to_end_vs_oracle(gpu):
         assert len(want) >= 5, "calibration should leave the oracle some detections"
 
         def matched(x, pool):
-            return any(c == x[2] and iou(x[0], b) >= 0.85 and abs(s - x[1]) < 0.03 for b, s, c in pool)
+            return any(c == x[2] and iou(x[0], b) >= 0.7 and abs(s - x[1]) < 0.03 for b, s, c in pool)
 
         sure_w = [x for x in want if x[1] > conf + 0.03]
         sure_g = [x for x in got if x[1] > conf + 0.03]
