@@ -65,6 +65,16 @@ SIGNATURES = {
     "eioku_yolo_postprocess": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int),
                                          C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eioku_index_flat_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "eioku_index_destroy": (None, [C.c_void_p]),
+    "eioku_index_ntotal": (C.c_longlong, [C.c_void_p]),
+    "eioku_index_reset": (C.c_int, [C.c_void_p]),
+    "eioku_index_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
+    "eioku_index_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "eioku_index_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p]),
+    "eioku_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
 }
 
 _lib = None

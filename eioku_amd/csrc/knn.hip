@@ -1,0 +1,566 @@
+// K9 l2_flat_topk: exact kNN over fp32 vectors (FAISS IndexFlatL2 semantics) on gfx950.
+//
+//   dist(q, x) = max(0, (|q|^2 + |x|^2) - 2 q.x)      squared L2, ascending, ids int64
+//
+// The dot products run on the exact-fp32 matrix core (v_mfma_f32_32x32x2_f32: a k-ordered fmaf
+// chain, no reduced-precision fast path exists on gfx950), which is what the 1e-4 relative bar on
+// distances needs.  One wave owns a 32-query tile whose 32 x d operand stays in registers for the
+// whole pass; it streams its share of the database through a private, XOR-swizzled LDS ring
+// (coalesced 256-B row segments from HBM, register-staged one chunk ahead) and reads each lane's
+// four consecutive k-steps with one conflict-free ds_read_b128.  The 32x32 distance tile lands with
+// the query on the lane, so every lane keeps a sorted top-K of the rows it has seen in registers:
+// a row only costs 16 compares unless it beats the lane's current K-th best.
+//
+// Per-(workgroup, query) partial lists are merged by k_topk_merge (also used for the cross-rank
+// merge after the RCCL all-gather).  Ties are broken by the smaller id everywhere.
+//
+// Algorithmic bytes: N*d*4 per 32-query pass; FLOPs 2*nq*N*d.
+#include "common.h"
+
+#include <cfloat>
+
+using namespace eioku;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kQT = 32;        // queries per wave tile (MFMA N)
+constexpr int kRT = 32;        // database rows per MFMA tile (MFMA M)
+constexpr int kKC = 64;        // dims per LDS chunk (256 B per row)
+constexpr int kWaves = 4;
+constexpr int kMaxD = 512;     // register budget: d/2 VGPRs hold the query tile
+
+template <int K>
+struct TopK {
+  float v[K];
+  int id[K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+      v[p] = FLT_MAX;
+      id[p] = 0x7FFFFFFF;
+    }
+  }
+  // keep ascending by (value, id); called only when (x, i) beats the tail
+  __device__ __forceinline__ void insert(float x, int i) {
+#pragma unroll
+    for (int p = K - 1; p > 0; --p) {
+      const bool shift = (v[p - 1] > x) || (v[p - 1] == x && id[p - 1] > i);
+      const bool here = !shift && ((v[p] > x) || (v[p] == x && id[p] > i));
+      const float nv = shift ? v[p - 1] : (here ? x : v[p]);
+      const int ni = shift ? id[p - 1] : (here ? i : id[p]);
+      v[p] = nv;
+      id[p] = ni;
+    }
+    if ((v[0] > x) || (v[0] == x && id[0] > i)) {
+      v[0] = x;
+      id[0] = i;
+    }
+  }
+  __device__ __forceinline__ bool beats_tail(float x, int i) const {
+    return (x < v[K - 1]) || (x == v[K - 1] && i < id[K - 1]);
+  }
+};
+
+struct KnnArgs {
+  const float* db;      // [n][d]
+  const float* dbnorm;  // [n]
+  const float* q;       // [nq][d]
+  const float* qnorm;   // [nq]
+  long long n;
+  int nq, d;
+  long long rows_per_block;  // multiple of kRT * kWaves
+  float* pd;                 // partial [gridDim.y][gridDim.x][kQT][K]
+  int* pi;
+  long long id_base;         // added to row ids at the very end (kept in merge)
+};
+
+// D = 32 x d query tile in registers, DB streamed through LDS.  grid = (db slabs, query tiles).
+template <int K, int D>
+__global__ __launch_bounds__(256, 1) void k_flat_l2(KnnArgs a) {
+  constexpr int NCH = D / kKC;          // chunks per row
+  constexpr int UPR = kKC / 4;          // 16-byte units per row chunk (16)
+  // 64 KB: four wave-private double buffers while streaming; reused for the final list merge
+  __shared__ __attribute__((aligned(16))) float4 lds[kWaves * 2 * kRT * UPR];
+  static_assert(sizeof(float) * 2 * kQT * kWaves * 2 * K <= sizeof(float4) * kWaves * 2 * kRT * UPR, "merge area");
+  float (*s_mv)[kWaves * 2][K] = reinterpret_cast<float (*)[kWaves * 2][K]>(lds);
+  int (*s_mi)[kWaves * 2][K] = reinterpret_cast<int (*)[kWaves * 2][K]>(reinterpret_cast<float*>(lds) + kQT * kWaves * 2 * K);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int qt = blockIdx.y;
+  const int qi = qt * kQT + col;
+  const bool qvalid = qi < a.nq;
+
+  // ---- query operand: Q[t][j] = q[col][8t + 4*half + j]  (same k permutation as the A reads) ----
+  float4 Q[D / 8];
+  {
+    const float* qp = a.q + (size_t)(qvalid ? qi : 0) * D + 4 * half;
+#pragma unroll
+    for (int t = 0; t < D / 8; ++t) {
+      Q[t] = *reinterpret_cast<const float4*>(qp + 8 * t);
+      if (!qvalid) Q[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float qn = qvalid ? a.qnorm[qi] : 0.f;
+
+  TopK<K> top;
+  top.init();
+
+  const long long slab0 = (long long)blockIdx.x * a.rows_per_block;
+  const long long slab1 = min(a.n, slab0 + a.rows_per_block);
+  float4* my = lds + wave * (2 * kRT * UPR);
+
+  // staging map: lane -> (row = it*4 + (lane>>4), unit = lane&15), 8 loads cover 32 rows x 256 B
+  const int srow = lane >> 4, sunit = lane & 15;
+  float4 stage[8];
+
+  auto issue = [&](long long row0, int ch) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const long long r = row0 + it * 4 + srow;
+      stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < slab1) stage[it] = *reinterpret_cast<const float4*>(a.db + (size_t)r * D + ch * kKC + sunit * 4);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + srow;
+      my[buf * (kRT * UPR) + row * UPR + (sunit ^ (row & 15))] = stage[it];
+    }
+    // other lanes of this wave read these bytes: keep the compiler from moving LDS ops across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // each wave walks its own row tiles: wave w takes tiles w, w+4, ... of the slab
+  for (long long row0 = slab0 + (long long)wave * kRT; row0 < slab1; row0 += (long long)kRT * kWaves) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    issue(row0, 0);
+    commit(0);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int buf = ch & 1;
+      if (ch + 1 < NCH) issue(row0, ch + 1);  // next chunk in flight during the MFMAs below
+      // wave-private buffer: LDS operations of one wave complete in order, no barrier needed
+#pragma unroll
+      for (int t = 0; t < kKC / 8; ++t) {
+        const int row = col;  // A row index = lane & 31
+        const float4 x = my[buf * (kRT * UPR) + row * UPR + ((2 * t + half) ^ (row & 15))];
+        const float4 qq = Q[ch * (kKC / 8) + t];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, qq.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, qq.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, qq.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, qq.w, acc, 0, 0, 0);
+      }
+      if (ch + 1 < NCH) commit(buf ^ 1);
+    }
+    // ---- distances + per-lane top-K: lane = query col, rows (r&3) + 8*(r>>2) + 4*half ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (row < slab1) {
+        float dist = (qn + a.dbnorm[row]) - 2.0f * acc[r];
+        dist = dist < 0.f ? 0.f : dist;
+        const int id = (int)(row - slab0);  // slab-local, fits 31 bits
+        if (top.beats_tail(dist, id)) top.insert(dist, id);
+      }
+    }
+  }
+
+  // ---- merge the 8 lists (4 waves x 2 halves) of each query inside the workgroup ----
+  __syncthreads();  // every wave is done with its staging buffers before they are reused
+#pragma unroll
+  for (int p = 0; p < K; ++p) {
+    s_mv[col][wave * 2 + half][p] = top.v[p];
+    s_mi[col][wave * 2 + half][p] = top.id[p];
+  }
+  __syncthreads();
+  if (tid < kQT) {
+    int head[kWaves * 2];
+#pragma unroll
+    for (int l = 0; l < kWaves * 2; ++l) head[l] = 0;
+    const size_t out = (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kQT + tid) * K;
+    for (int p = 0; p < K; ++p) {
+      float bv = FLT_MAX;
+      int bi = 0x7FFFFFFF, bl = 0;
+#pragma unroll
+      for (int l = 0; l < kWaves * 2; ++l) {
+        if (head[l] < K) {
+          const float v = s_mv[tid][l][head[l]];
+          const int i = s_mi[tid][l][head[l]];
+          if (v < bv || (v == bv && i < bi)) {
+            bv = v;
+            bi = i;
+            bl = l;
+          }
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < kWaves * 2; ++l)
+        if (l == bl) head[l]++;
+      a.pd[out + p] = bv;
+      // global id, or -1 when fewer than K rows exist
+      a.pi[out + p] = bi == 0x7FFFFFFF ? -1 : bi;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_row_norms(const float* x, long long n, int d, float* out) {
+  const int lane = threadIdx.x & 63;
+  long long row = (blockIdx.x * 256ll + threadIdx.x) >> 6;
+  const long long nw = ((long long)gridDim.x * 256) >> 6;
+  for (; row < n; row += nw) {
+    float s = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * d + c);
+      s += v.x * v.x;
+      s += v.y * v.y;
+      s += v.z * v.z;
+      s += v.w * v.w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) out[row] = s;
+  }
+}
+
+// Merge L sorted lists of Kin (value, local id) per query into the k best (value, id) ascending.
+// One wave per query: lanes stride over the lists keeping a register top-K, then K rounds of
+// wave-wide argmin pop the winners.  `list_base[l]` (optional) is added to the ids of list l.
+template <int K>
+__global__ __launch_bounds__(64) void k_topk_merge(const float* pd, const int* pi, const long long* pi64,
+                                                   int L, int nq, int kin, int qstride_lists,
+                                                   const long long* list_base, long long rows_per_list,
+                                                   int k, float* D, long long* I) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  // partial layout: [qtile][list][kQT][kin] when qstride_lists > 0 (search partials), else [list][nq][kin]
+  TopK<K> top;
+  top.init();
+  long long gid[K];
+#pragma unroll
+  for (int p = 0; p < K; ++p) gid[p] = -1;
+  for (int l = lane; l < L; l += 64) {
+    size_t base;
+    if (qstride_lists > 0) base = ((((size_t)(q / kQT) * L + l) * kQT) + (q % kQT)) * kin;
+    else base = ((size_t)l * nq + q) * kin;
+    for (int p = 0; p < kin; ++p) {
+      const float v = pd[base + p];
+      long long id;
+      if (pi64) id = pi64[base + p];
+      else {
+        const int li = pi[base + p];
+        id = li < 0 ? -1 : (long long)li + (list_base ? list_base[l] : (long long)l * rows_per_list);
+      }
+      if (id < 0) break;  // lists are sorted: the rest is padding
+      // TopK keeps 31-bit ids for the tie rule; carry the 64-bit id alongside via the slot it lands in
+      const bool better_tail = (v < top.v[K - 1]) || (v == top.v[K - 1] && id < gid[K - 1]) || gid[K - 1] < 0;
+      if (!better_tail) break;  // ascending list: nothing later can enter either
+#pragma unroll
+      for (int s = K - 1; s > 0; --s) {
+        const bool shift = gid[s - 1] < 0 || (top.v[s - 1] > v) || (top.v[s - 1] == v && gid[s - 1] > id);
+        const bool here = !shift && (gid[s] < 0 || (top.v[s] > v) || (top.v[s] == v && gid[s] > id));
+        const float nv = shift ? top.v[s - 1] : (here ? v : top.v[s]);
+        const long long ni = shift ? gid[s - 1] : (here ? id : gid[s]);
+        top.v[s] = nv;
+        gid[s] = ni;
+      }
+      if (gid[0] < 0 || (top.v[0] > v) || (top.v[0] == v && gid[0] > id)) {
+        top.v[0] = v;
+        gid[0] = id;
+      }
+    }
+  }
+  // K rounds of wave argmin over the list heads
+  for (int r = 0; r < k; ++r) {
+    float bv = gid[0] < 0 ? FLT_MAX : top.v[0];
+    long long bi = gid[0] < 0 ? 0x7FFFFFFFFFFFFFFFll : gid[0];
+    int bl = lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const long long oi = __shfl_xor(bi, off, 64);
+      const int ol = __shfl_xor(bl, off, 64);
+      if (ov < bv || (ov == bv && oi < bi) || (ov == bv && oi == bi && ol < bl)) {
+        bv = ov;
+        bi = oi;
+        bl = ol;
+      }
+    }
+    const bool found = bi != 0x7FFFFFFFFFFFFFFFll;
+    if (lane == 0) {
+      D[(size_t)q * k + r] = found ? bv : FLT_MAX;
+      I[(size_t)q * k + r] = found ? bi : -1;
+    }
+    if (found && lane == bl) {  // pop
+#pragma unroll
+      for (int s = 0; s < K - 1; ++s) {
+        top.v[s] = top.v[s + 1];
+        gid[s] = gid[s + 1];
+      }
+      top.v[K - 1] = FLT_MAX;
+      gid[K - 1] = -1;
+    }
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+struct eioku_index {
+  int d = 0;
+  long long n = 0, cap = 0;
+  float* x = nullptr;      // owned unless attached
+  float* norms = nullptr;  // owned
+  long long norms_cap = 0;
+  bool attached = false;
+  // search workspace
+  float* qbuf = nullptr; size_t qcap = 0;
+  float* qnorm = nullptr; size_t qncap = 0;
+  float* pd = nullptr; size_t pdcap = 0;
+  int* pi = nullptr; size_t picap = 0;
+  float* dout = nullptr; size_t dcap = 0;
+  long long* iout = nullptr; size_t icap = 0;
+};
+
+namespace {
+
+template <typename T>
+int grow(T** p, size_t* cap, size_t bytes) {
+  if (*cap >= bytes) return EIOKU_OK;
+  if (*p) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+  }
+  EIOKU_HIP_CHECK(hipMalloc((void**)p, bytes));
+  *cap = bytes;
+  return EIOKU_OK;
+}
+
+int norms_for(const float* x, long long n, int d, float* out, hipStream_t stream) {
+  if (n == 0) return EIOKU_OK;
+  long long blocks = (n * 64 + 255) / 256;
+  const long long cap = (long long)num_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, d, out);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+template <int K>
+int launch_search_k(int d, const KnnArgs& a, dim3 grid, hipStream_t stream) {
+  switch (d) {
+    case 64: hipLaunchKernelGGL((k_flat_l2<K, 64>), grid, dim3(256), 0, stream, a); break;
+    case 128: hipLaunchKernelGGL((k_flat_l2<K, 128>), grid, dim3(256), 0, stream, a); break;
+    case 256: hipLaunchKernelGGL((k_flat_l2<K, 256>), grid, dim3(256), 0, stream, a); break;
+    case 384: hipLaunchKernelGGL((k_flat_l2<K, 384>), grid, dim3(256), 0, stream, a); break;
+    case 512: hipLaunchKernelGGL((k_flat_l2<K, 512>), grid, dim3(256), 0, stream, a); break;
+    default:
+      set_error("dimension %d not supported (64, 128, 256, 384, 512)", d);
+      return EIOKU_EINVAL;
+  }
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eioku_index_flat_create(int d, eioku_index** out) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(out, "NULL out");
+  EIOKU_REQUIRE(d == 64 || d == 128 || d == 256 || d == 384 || d == 512,
+                "dimension %d not supported (64, 128, 256, 384, 512)", d);
+  auto* ix = new eioku_index();
+  ix->d = d;
+  *out = ix;
+  return EIOKU_OK;
+}
+
+void eioku_index_destroy(eioku_index* ix) {
+  if (!ix) return;
+  (void)hipDeviceSynchronize();
+  if (ix->x && !ix->attached) (void)hipFree(ix->x);
+  void* bufs[] = {ix->norms, ix->qbuf, ix->qnorm, ix->pd, ix->pi, ix->dout, ix->iout};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  delete ix;
+}
+
+long long eioku_index_ntotal(const eioku_index* ix) { return ix ? ix->n : 0; }
+
+int eioku_index_reset(eioku_index* ix) {
+  EIOKU_REQUIRE(ix, "NULL index");
+  if (ix->attached) {
+    ix->x = nullptr;
+    ix->attached = false;
+    ix->cap = 0;
+  }
+  ix->n = 0;
+  return EIOKU_OK;
+}
+
+int eioku_index_add(eioku_index* ix, const float* x, long long n, int mem, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(ix && (x || n == 0) && n >= 0, "bad argument");
+  EIOKU_REQUIRE(!ix->attached, "index wraps an attached buffer; reset it before add()");
+  EIOKU_REQUIRE(mem == EIOKU_MEM_HOST || mem == EIOKU_MEM_DEVICE, "bad mem flag %d", mem);
+  if (n == 0) return EIOKU_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const long long need = ix->n + n;
+  if (need > ix->cap) {
+    long long ncap = ix->cap ? ix->cap : 1024;
+    while (ncap < need) ncap *= 2;
+    float* nx = nullptr;
+    EIOKU_HIP_CHECK(hipMalloc((void**)&nx, (size_t)ncap * ix->d * sizeof(float)));
+    if (ix->n) EIOKU_HIP_CHECK(hipMemcpy(nx, ix->x, (size_t)ix->n * ix->d * sizeof(float), hipMemcpyDeviceToDevice));
+    if (ix->x) (void)hipFree(ix->x);
+    ix->x = nx;
+    float* nn = nullptr;
+    EIOKU_HIP_CHECK(hipMalloc((void**)&nn, (size_t)ncap * sizeof(float)));
+    if (ix->n) EIOKU_HIP_CHECK(hipMemcpy(nn, ix->norms, (size_t)ix->n * sizeof(float), hipMemcpyDeviceToDevice));
+    if (ix->norms) (void)hipFree(ix->norms);
+    ix->norms = nn;
+    ix->norms_cap = ncap;
+    ix->cap = ncap;
+  }
+  float* dst = ix->x + (size_t)ix->n * ix->d;
+  EIOKU_HIP_CHECK(hipMemcpyAsync(dst, x, (size_t)n * ix->d * sizeof(float),
+                                 mem == EIOKU_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, stream));
+  int rc = norms_for(dst, n, ix->d, ix->norms + ix->n, stream);
+  if (rc) return rc;
+  ix->n = need;
+  if (mem == EIOKU_MEM_HOST) EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
+  return EIOKU_OK;
+}
+
+int eioku_index_attach(eioku_index* ix, float* x_dev, long long n, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(ix && x_dev && n >= 0, "bad argument");
+  EIOKU_REQUIRE(((uintptr_t)x_dev & 15) == 0, "attached buffer must be 16-byte aligned");
+  if (ix->x && !ix->attached) (void)hipFree(ix->x);
+  ix->x = x_dev;
+  ix->attached = true;
+  ix->n = n;
+  ix->cap = n;
+  if (ix->norms_cap < n) {
+    if (ix->norms) (void)hipFree(ix->norms);
+    ix->norms = nullptr;
+    EIOKU_HIP_CHECK(hipMalloc((void**)&ix->norms, (size_t)(n ? n : 1) * sizeof(float)));
+    ix->norms_cap = n;
+  }
+  return norms_for(x_dev, n, ix->d, ix->norms, (hipStream_t)stream_);
+}
+
+int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D, int64_t* I, int mem,
+                       void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(ix && nq >= 0 && k >= 1, "bad argument");
+  EIOKU_REQUIRE(k <= 32, "k=%d not supported (k <= 32)", k);
+  EIOKU_REQUIRE(mem == EIOKU_MEM_HOST || mem == EIOKU_MEM_DEVICE, "bad mem flag %d", mem);
+  if (nq == 0) return EIOKU_OK;
+  EIOKU_REQUIRE(q && D && I, "NULL buffer");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int d = ix->d;
+  const int K = k <= 16 ? 16 : 32;
+  const int qtiles = (nq + kQT - 1) / kQT;
+  // slabs: ~4 workgroups per CU over the whole grid, slab a multiple of 128 rows
+  long long want = (long long)num_cus() * 4 / qtiles;
+  if (want < 1) want = 1;
+  long long rpb = (ix->n + want - 1) / want;
+  rpb = ((rpb + kRT * kWaves - 1) / (kRT * kWaves)) * (kRT * kWaves);
+  if (rpb < kRT * kWaves) rpb = kRT * kWaves;
+  const long long slabs = ix->n ? (ix->n + rpb - 1) / rpb : 1;
+  EIOKU_REQUIRE(rpb < (1ll << 31), "slab too large");
+
+  int rc;
+  const float* dq = q;
+  if (mem == EIOKU_MEM_HOST) {
+    rc = grow(&ix->qbuf, &ix->qcap, (size_t)nq * d * sizeof(float));
+    if (rc) return rc;
+    EIOKU_HIP_CHECK(hipMemcpyAsync(ix->qbuf, q, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, stream));
+    dq = ix->qbuf;
+  }
+  EIOKU_REQUIRE(((uintptr_t)dq & 15) == 0, "queries must be 16-byte aligned");
+  rc = grow(&ix->qnorm, &ix->qncap, (size_t)nq * sizeof(float));
+  if (rc) return rc;
+  rc = norms_for(dq, nq, d, ix->qnorm, stream);
+  if (rc) return rc;
+  const size_t pn = (size_t)qtiles * slabs * kQT * K;
+  rc = grow(&ix->pd, &ix->pdcap, pn * sizeof(float));
+  if (rc) return rc;
+  rc = grow(&ix->pi, &ix->picap, pn * sizeof(int));
+  if (rc) return rc;
+  float* dD = D;
+  long long* dI = (long long*)I;
+  if (mem == EIOKU_MEM_HOST) {
+    rc = grow(&ix->dout, &ix->dcap, (size_t)nq * k * sizeof(float));
+    if (rc) return rc;
+    rc = grow(&ix->iout, &ix->icap, (size_t)nq * k * sizeof(long long));
+    if (rc) return rc;
+    dD = ix->dout;
+    dI = ix->iout;
+  }
+  KnnArgs a;
+  a.db = ix->x;
+  a.dbnorm = ix->norms;
+  a.q = dq;
+  a.qnorm = ix->qnorm;
+  a.n = ix->n;
+  a.nq = nq;
+  a.d = d;
+  a.rows_per_block = rpb;
+  a.pd = ix->pd;
+  a.pi = ix->pi;
+  a.id_base = 0;
+  dim3 grid((unsigned)slabs, (unsigned)qtiles);
+  prof_start(EIOKU_PROF_KNN, stream);
+  rc = K == 16 ? launch_search_k<16>(d, a, grid, stream) : launch_search_k<32>(d, a, grid, stream);
+  prof_stop(EIOKU_PROF_KNN, stream);
+  if (rc) return rc;
+  if (K == 16)
+    hipLaunchKernelGGL((k_topk_merge<16>), dim3(nq), dim3(64), 0, stream, ix->pd, ix->pi, (const long long*)nullptr,
+                       (int)slabs, nq, K, 1, (const long long*)nullptr, rpb, k, dD, dI);
+  else
+    hipLaunchKernelGGL((k_topk_merge<32>), dim3(nq), dim3(64), 0, stream, ix->pd, ix->pi, (const long long*)nullptr,
+                       (int)slabs, nq, K, 1, (const long long*)nullptr, rpb, k, dD, dI);
+  EIOKU_LAUNCH_CHECK();
+  if (mem == EIOKU_MEM_HOST) {
+    EIOKU_HIP_CHECK(hipMemcpyAsync(D, dD, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, stream));
+    EIOKU_HIP_CHECK(hipMemcpyAsync(I, dI, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, stream));
+    EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return EIOKU_OK;
+}
+
+// Merge `nlists` per-shard results (each [nq][k] ascending, ids already global, -1 = empty) into the
+// global top-k.  Device pointers; d_lists / i_lists are [nlists][nq][k] contiguous (the layout an
+// all-gather of per-rank (D, I) produces).
+int eioku_topk_merge(const float* d_lists, const int64_t* i_lists, int nlists, int nq, int k, float* D,
+                     int64_t* I, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(nlists >= 1 && nq >= 0 && k >= 1 && k <= 32, "bad argument");
+  if (nq == 0) return EIOKU_OK;
+  EIOKU_REQUIRE(d_lists && i_lists && D && I, "NULL buffer");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (k <= 16)
+    hipLaunchKernelGGL((k_topk_merge<16>), dim3(nq), dim3(64), 0, stream, d_lists, (const int*)nullptr,
+                       (const long long*)i_lists, nlists, nq, k, 0, (const long long*)nullptr, 0ll, k, D, (long long*)I);
+  else
+    hipLaunchKernelGGL((k_topk_merge<32>), dim3(nq), dim3(64), 0, stream, d_lists, (const int*)nullptr,
+                       (const long long*)i_lists, nlists, nq, k, 0, (const long long*)nullptr, 0ll, k, D, (long long*)I);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+}  // extern "C"

@@ -187,6 +187,28 @@ int eioku_yolo_postprocess(const float* const* box_dev, const float* const* cls_
                            int pad_x, int pad_y, int src_w, int src_h, void* dets_dev,
                            int32_t* counts_dev, void* stream);
 
+/* ---- semantic search: exact kNN (FAISS IndexFlatL2 semantics) -----------------------------
+ * The reference holds intent only for this stage (.kiro/specs/semantic-video-search/design.md:
+ * 35-40,1105-1113; tasks.md:304-313 unchecked); BASELINE.json's north_star names FAISS IndexFlatL2.
+ * search() returns SQUARED L2 distances ascending and int64 ids (-1 / FLT_MAX when fewer than k
+ * vectors exist), ties broken by the smaller id.  d in {64,128,256,384,512}, k <= 32.
+ */
+typedef struct eioku_index eioku_index_t;
+int eioku_index_flat_create(int d, eioku_index_t** out);
+void eioku_index_destroy(eioku_index_t* ix);
+long long eioku_index_ntotal(const eioku_index_t* ix);
+int eioku_index_reset(eioku_index_t* ix);
+/* append n vectors (host: staged; device: copied into the index' own HBM buffer) */
+int eioku_index_add(eioku_index_t* ix, const float* x, long long n, int mem, void* stream);
+/* zero-copy: search an existing 16-byte aligned device buffer of n x d floats (bench: 10M x 384) */
+int eioku_index_attach(eioku_index_t* ix, float* x_dev, long long n, void* stream);
+int eioku_index_search(eioku_index_t* ix, const float* q, int nq, int k, float* D, int64_t* I, int mem,
+                       void* stream);
+/* C1 helper: merge nlists per-shard results [nlists][nq][k] (ids already global) -> [nq][k].
+ * Device pointers.  Used after the RCCL all-gather of per-rank (D, I). */
+int eioku_topk_merge(const float* d_lists, const int64_t* i_lists, int nlists, int nq, int k, float* D,
+                     int64_t* I, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,23 @@ def scene_fixtures():
     np.savez_compressed(HERE / "hsv_lattice.npz", bgr=bgr, hsv=scene.bgr2hsv_u8(bgr))
 
 
+def unit_rows(seed, n, d):
+    """Unit-norm rows from the portable PRNG (float64 norm, so the bytes do not depend on BLAS)."""
+    x = prng.approx_normal_f32(seed, n * d).reshape(n, d)
+    return (x / np.sqrt((x.astype(np.float64) ** 2).sum(1, keepdims=True))).astype(np.float32)
+
+
+def knn_fixtures():
+    from oracle import knn
+
+    xb, xq = unit_rows(21, 4096, 384), unit_rows(22, 16, 384)
+    D, I = knn.search(xb, xq, 10)
+    # inputs are regenerated from the seeds; a checksum guards against PRNG drift
+    np.savez_compressed(HERE / "flatl2_4096x384.npz", seed_db=21, seed_q=22, n=4096, nq=16, d=384, D=D, I=I,
+                        xb_sum=np.float64(xb.astype(np.float64).sum()), xq_first=xq[0, :8])
+
+
 if __name__ == "__main__":
     scene_fixtures()
+    knn_fixtures()
     print("wrote oracle fixtures to", HERE)
