@@ -75,6 +75,15 @@ SIGNATURES = {
                                      C.c_void_p]),
     "eioku_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "eioku_bert_create": (C.c_int, [C.c_int] * 7 + [C.c_float, C.POINTER(C.c_void_p)]),
+    "eioku_bert_destroy": (None, [C.c_void_p]),
+    "eioku_bert_num_tensors": (C.c_int, [C.c_void_p]),
+    "eioku_bert_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int)]),
+    "eioku_bert_set_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "eioku_bert_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p]),
+    "eioku_bert_last_flops": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
 }
 
 _lib = None

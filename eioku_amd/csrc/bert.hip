@@ -1,0 +1,552 @@
+// K8: all-MiniLM-L6-v2 style BERT encoder + masked mean pooling + L2 normalisation (gfx950).
+//
+// The reference holds intent only for this stage (.kiro/specs/semantic-video-search/design.md:54-57,
+// 1096-1103); BASELINE.json asks for embeddings within 1e-4 relative of the fp32 CPU path, so every
+// matmul runs on the exact-fp32 matrix core (v_mfma_f32_32x32x2_f32; there is no TF32-like mode on
+// gfx950) with LayerNorm / softmax / GELU(erf) in fp32.
+//
+//   k_embed_ln     word + position + token_type(0) embedding gather, LayerNorm        (HBM-bound)
+//   k_gemm_f32     C = A . W^T + bias [, GELU]   128x128x32 tiles, 4 waves x (2x2) 32x32 MFMA tiles,
+//                  register-staged double-buffered LDS, XOR-swizzled for ds_read_b128    (MFMA-bound)
+//   k_attention    per (segment, head): two-pass softmax(QK^T/sqrt(dh) + mask) V, K/V in LDS
+//   k_add_ln       LayerNorm(x + residual)
+//   k_pool_norm    attention-mask weighted mean over tokens, then x / max(|x|, 1e-12)
+#include "common.h"
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+using namespace eioku;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm helpers: one wave per token row, H <= 1024, H % 64 == 0
+// ---------------------------------------------------------------------------------------------
+template <int MAXV>
+__device__ __forceinline__ void wave_layernorm(float (&x)[MAXV], int nv, int H, const float* __restrict__ g,
+                                               const float* __restrict__ b, float eps, float* __restrict__ out,
+                                               int lane) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) s += x[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)H;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) {
+      const float d = x[i] - mean;
+      v += d * d;
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const float rstd = 1.0f / sqrtf(v / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) {
+      const int c = lane + 64 * i;
+      out[c] = (x[i] - mean) * rstd * g[c] + b[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ ids, int T, int S, int H, int vocab,
+                                                  const float* __restrict__ wemb, const float* __restrict__ pemb,
+                                                  const float* __restrict__ temb, const float* __restrict__ g,
+                                                  const float* __restrict__ b, float eps, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int t = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (t >= T) return;
+  int id = ids[t];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // checked on the host as well
+  const int pos = t % S;
+  float x[16];
+  const int nv = H / 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < nv) {
+      const int c = lane + 64 * i;
+      x[i] = (wemb[(size_t)id * H + c] + temb[c]) + pemb[(size_t)pos * H + c];
+    }
+  wave_layernorm<16>(x, nv, H, g, b, eps, out + (size_t)t * H, lane);
+}
+
+__global__ __launch_bounds__(256) void k_add_ln(const float* __restrict__ a, const float* __restrict__ r, int T,
+                                                int H, const float* __restrict__ g, const float* __restrict__ b,
+                                                float eps, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int t = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (t >= T) return;
+  float x[16];
+  const int nv = H / 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < nv) {
+      const int c = lane + 64 * i;
+      x[i] = a[(size_t)t * H + c] + r[(size_t)t * H + c];
+    }
+  wave_layernorm<16>(x, nv, H, g, b, eps, out + (size_t)t * H, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM: C[M][N] = A[M][K] . W[N][K]^T + bias[N]  (+ GELU).  N % 128 == 0, K % 32 == 0.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBM = 128, kBN = 128, kBK = 32;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int EPI>  // 0: bias, 1: bias + GELU
+__global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                     int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) float4 sA[2][kBM * 8];
+  __shared__ __attribute__((aligned(16))) float4 sW[2][kBN * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * kBM, n0 = blockIdx.y * kBN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging map: 4 rows per thread, unit = tid & 7, rows (tid>>3) + 32*it
+  const int sunit = tid & 7, srow = tid >> 3;
+  float4 ra[4], rw[4];
+  auto issue = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = srow + 32 * it;
+      const int m = m0 + row;
+      ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) ra[it] = *reinterpret_cast<const float4*>(A + (size_t)m * lda + kc * kBK + sunit * 4);
+      rw[it] = *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * K + kc * kBK + sunit * 4);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = srow + 32 * it;
+      const int pos = row * 8 + (sunit ^ ((row >> 1) & 7));
+      sA[buf][pos] = ra[it];
+      sW[buf][pos] = rw[it];
+    }
+  };
+
+  const int nk = K / kBK;
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) issue(kc + 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float4 a[2], w[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + l31;
+        a[i] = sA[buf][row * 8 + ((2 * t + half) ^ ((row >> 1) & 7))];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = wn * 64 + j * 32 + l31;
+        w[j] = sW[buf][row * 8 + ((2 * t + half) ^ ((row >> 1) & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, w[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, w[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, w[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, w[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kc + 1 < nk) commit(buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: lane = column n, registers = rows m
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + l31;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < M) {
+          float v = acc[i][j][r] + bv;
+          if (EPI == 1) v = gelu_erf(v);
+          C[(size_t)m * ldc + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention: grid (B, heads), block = S threads rounded to 64 (S <= 512), head_dim == 32
+// qkv: [B*S][3H] with Q | K | V column blocks; ctx: [B*S][H]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_attention(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                   int S, int H, float* __restrict__ ctx) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float4* sK = reinterpret_cast<float4*>(sm);       // [S][8]
+  float4* sV = sK + (size_t)S * 8;                  // [S][8]
+  float* sM = reinterpret_cast<float*>(sV + (size_t)S * 8);  // [S] 1/0
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const size_t row0 = (size_t)b * S;
+  for (int i = tid; i < S * 8; i += blockDim.x) {
+    const int j = i >> 3, u = i & 7;
+    const float* base = qkv + (row0 + j) * (size_t)(3 * H) + h * 32 + u * 4;
+    sK[i] = *reinterpret_cast<const float4*>(base + H);
+    sV[i] = *reinterpret_cast<const float4*>(base + 2 * H);
+  }
+  for (int j = tid; j < S; j += blockDim.x) sM[j] = mask[row0 + j] ? 1.f : 0.f;
+  __syncthreads();
+  if (tid >= S) return;
+  float q[32];
+  {
+    const float* qp = qkv + (row0 + tid) * (size_t)(3 * H) + h * 32;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float4 v = *reinterpret_cast<const float4*>(qp + u * 4);
+      q[u * 4] = v.x; q[u * 4 + 1] = v.y; q[u * 4 + 2] = v.z; q[u * 4 + 3] = v.w;
+    }
+  }
+  const float inv = 5.65685424949238f;  // sqrt(32): scores / sqrt(head_size)
+  auto score = [&](int j) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float4 k = sK[j * 8 + u];
+      s += q[u * 4] * k.x;
+      s += q[u * 4 + 1] * k.y;
+      s += q[u * 4 + 2] * k.z;
+      s += q[u * 4 + 3] * k.w;
+    }
+    return s / inv;
+  };
+  float mx = -INFINITY;
+  for (int j = 0; j < S; ++j)
+    if (sM[j] != 0.f) mx = fmaxf(mx, score(j));
+  float acc[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+  float l = 0.f;
+  for (int j = 0; j < S; ++j) {
+    if (sM[j] == 0.f) continue;
+    const float e = expf(score(j) - mx);
+    l += e;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float4 v = sV[j * 8 + u];
+      acc[u * 4] += e * v.x;
+      acc[u * 4 + 1] += e * v.y;
+      acc[u * 4 + 2] += e * v.z;
+      acc[u * 4 + 3] += e * v.w;
+    }
+  }
+  float* op = ctx + (row0 + tid) * (size_t)H + h * 32;
+  const float rl = l > 0.f ? 1.0f / l : 0.f;  // fully masked segment -> zeros (its pooled vector is 0 anyway)
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    *reinterpret_cast<float4*>(op + u * 4) =
+        make_float4(acc[u * 4] * rl, acc[u * 4 + 1] * rl, acc[u * 4 + 2] * rl, acc[u * 4 + 3] * rl);
+}
+
+// mean pooling (mask weighted) + L2 normalise; one block (H threads) per segment
+__global__ __launch_bounds__(1024) void k_pool_norm(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                    int S, int H, float* __restrict__ out) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, c = threadIdx.x;
+  float s = 0.f, cnt = 0.f;
+  for (int t = 0; t < S; ++t) {
+    const float m = mask[(size_t)b * S + t] ? 1.f : 0.f;
+    cnt += m;
+    if (c < H) s += x[((size_t)b * S + t) * H + c] * m;
+  }
+  const float v = c < H ? s / fmaxf(cnt, 1e-9f) : 0.f;
+  float sq = v * v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+  if ((c & 63) == 0) red[c >> 6] = sq;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+  const float nrm = fmaxf(sqrtf(tot), 1e-12f);
+  if (c < H) out[(size_t)b * H + c] = v / nrm;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+struct eioku_bert {
+  int vocab, H, L, heads, ffn, max_pos, type_vocab;
+  float eps;
+  struct Tensor {
+    std::string name;
+    std::vector<int> shape;
+    float* dev = nullptr;
+    bool set = false;
+    size_t numel() const {
+      size_t n = 1;
+      for (int s : shape) n *= s;
+      return n;
+    }
+  };
+  std::vector<Tensor> tensors;
+  // workspace
+  int32_t* d_ids = nullptr; size_t ids_cap = 0;
+  uint8_t* d_mask = nullptr; size_t mask_cap = 0;
+  float* x = nullptr; float* y = nullptr; float* qkv = nullptr; float* ctx = nullptr; float* mid = nullptr;
+  size_t x_cap = 0, y_cap = 0, qkv_cap = 0, ctx_cap = 0, mid_cap = 0;
+  float* d_out = nullptr; size_t out_cap = 0;
+  double flops_last = 0;
+};
+
+namespace {
+
+template <typename T>
+int grow(T** p, size_t* cap, size_t bytes) {
+  if (*cap >= bytes) return EIOKU_OK;
+  if (*p) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+  }
+  EIOKU_HIP_CHECK(hipMalloc((void**)p, bytes));
+  *cap = bytes;
+  return EIOKU_OK;
+}
+
+int find(const eioku_bert* m, const std::string& name) {
+  for (size_t i = 0; i < m->tensors.size(); ++i)
+    if (m->tensors[i].name == name) return (int)i;
+  return -1;
+}
+
+const float* tp(const eioku_bert* m, const std::string& name) { return m->tensors[find(m, name)].dev; }
+
+int gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int epi,
+         hipStream_t stream) {
+  EIOKU_REQUIRE(N % kBN == 0 && K % kBK == 0, "gemm shape N=%d K=%d must be multiples of 128 / 32", N, K);
+  dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)(N / kBN));
+  prof_start(EIOKU_PROF_GEMM, stream);
+  if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
+  else hipLaunchKernelGGL((k_gemm_f32<0>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
+  prof_stop(EIOKU_PROF_GEMM, stream);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eioku_bert_create(int vocab, int hidden, int layers, int heads, int ffn, int max_pos, int type_vocab,
+                      float ln_eps, eioku_bert** out) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(out, "NULL out");
+  EIOKU_REQUIRE(hidden % 128 == 0 && hidden <= 1024, "hidden %d must be a multiple of 128 and <= 1024", hidden);
+  EIOKU_REQUIRE(heads > 0 && hidden / heads == 32 && hidden % heads == 0, "head_dim must be 32 (hidden %d / heads %d)", hidden, heads);
+  EIOKU_REQUIRE(ffn % 128 == 0, "ffn %d must be a multiple of 128", ffn);
+  EIOKU_REQUIRE(vocab > 0 && layers > 0 && max_pos > 0 && type_vocab > 0, "bad config");
+  auto* m = new eioku_bert();
+  m->vocab = vocab; m->H = hidden; m->L = layers; m->heads = heads; m->ffn = ffn; m->max_pos = max_pos;
+  m->type_vocab = type_vocab; m->eps = ln_eps;
+  auto add = [&](const std::string& n, std::vector<int> shape) {
+    eioku_bert::Tensor t;
+    t.name = n;
+    t.shape = std::move(shape);
+    m->tensors.push_back(t);
+  };
+  const int H = hidden;
+  add("embeddings.word_embeddings.weight", {vocab, H});
+  add("embeddings.position_embeddings.weight", {max_pos, H});
+  add("embeddings.token_type_embeddings.weight", {type_vocab, H});
+  add("embeddings.LayerNorm.weight", {H});
+  add("embeddings.LayerNorm.bias", {H});
+  for (int l = 0; l < layers; ++l) {
+    const std::string p = "encoder.layer." + std::to_string(l) + ".";
+    // query | key | value stacked into one [3H][H] operand (one GEMM), filled through three sub-tensors
+    add(p + "attention.self.query.weight", {H, H});
+    add(p + "attention.self.key.weight", {H, H});
+    add(p + "attention.self.value.weight", {H, H});
+    add(p + "attention.self.query.bias", {H});
+    add(p + "attention.self.key.bias", {H});
+    add(p + "attention.self.value.bias", {H});
+    add(p + "attention.output.dense.weight", {H, H});
+    add(p + "attention.output.dense.bias", {H});
+    add(p + "attention.output.LayerNorm.weight", {H});
+    add(p + "attention.output.LayerNorm.bias", {H});
+    add(p + "intermediate.dense.weight", {ffn, H});
+    add(p + "intermediate.dense.bias", {ffn});
+    add(p + "output.dense.weight", {H, ffn});
+    add(p + "output.dense.bias", {H});
+    add(p + "output.LayerNorm.weight", {H});
+    add(p + "output.LayerNorm.bias", {H});
+  }
+  // allocate; q/k/v weights and biases of a layer are contiguous so the fused GEMM can use them in place
+  for (size_t i = 0; i < m->tensors.size(); ++i) {
+    auto& t = m->tensors[i];
+    const bool qw = t.name.find("attention.self.query.weight") != std::string::npos;
+    const bool qb = t.name.find("attention.self.query.bias") != std::string::npos;
+    if (qw || qb) {
+      const size_t n = t.numel();
+      float* base = nullptr;
+      if (hipMalloc((void**)&base, 3 * n * sizeof(float)) != hipSuccess) {
+        set_error("hipMalloc failed for %s", t.name.c_str());
+        return EIOKU_ENOMEM;
+      }
+      m->tensors[i].dev = base;
+      m->tensors[i + 1].dev = base + n;
+      m->tensors[i + 2].dev = base + 2 * n;
+    } else if (!t.dev) {
+      if (hipMalloc((void**)&t.dev, t.numel() * sizeof(float)) != hipSuccess) {
+        set_error("hipMalloc failed for %s", t.name.c_str());
+        return EIOKU_ENOMEM;
+      }
+    }
+  }
+  *out = m;
+  return EIOKU_OK;
+}
+
+void eioku_bert_destroy(eioku_bert* m) {
+  if (!m) return;
+  (void)hipDeviceSynchronize();
+  for (size_t i = 0; i < m->tensors.size(); ++i) {
+    const auto& n = m->tensors[i].name;
+    const bool sub = n.find("self.key.") != std::string::npos || n.find("self.value.") != std::string::npos;
+    if (!sub && m->tensors[i].dev) (void)hipFree(m->tensors[i].dev);
+  }
+  void* bufs[] = {m->d_ids, m->d_mask, m->x, m->y, m->qkv, m->ctx, m->mid, m->d_out};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  delete m;
+}
+
+int eioku_bert_num_tensors(const eioku_bert* m) { return m ? (int)m->tensors.size() : 0; }
+
+int eioku_bert_tensor_info(const eioku_bert* m, int idx, char* name, size_t cap, int* rows, int* cols) {
+  EIOKU_REQUIRE(m && idx >= 0 && idx < (int)m->tensors.size(), "bad tensor index %d", idx);
+  const auto& t = m->tensors[idx];
+  if (name && cap) snprintf(name, cap, "%s", t.name.c_str());
+  if (rows) *rows = t.shape[0];
+  if (cols) *cols = t.shape.size() > 1 ? t.shape[1] : 1;
+  return EIOKU_OK;
+}
+
+int eioku_bert_set_tensor(eioku_bert* m, int idx, const float* host, size_t numel) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(m && idx >= 0 && idx < (int)m->tensors.size() && host, "bad argument");
+  auto& t = m->tensors[idx];
+  EIOKU_REQUIRE(numel == t.numel(), "%s: expected %zu elements, got %zu", t.name.c_str(), t.numel(), numel);
+  EIOKU_HIP_CHECK(hipMemcpy(t.dev, host, numel * sizeof(float), hipMemcpyHostToDevice));
+  t.set = true;
+  return EIOKU_OK;
+}
+
+// ids: int32 [B][S] (0-padded), mask: uint8 [B][S]; out: float32 [B][H] unit vectors.
+int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int B, int S, float* out, int mem,
+                     void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(m && B >= 0 && S > 0, "bad argument");
+  EIOKU_REQUIRE(S <= m->max_pos && S <= 512, "sequence length %d exceeds max positions %d / 512", S, m->max_pos);
+  EIOKU_REQUIRE(mem == EIOKU_MEM_HOST || mem == EIOKU_MEM_DEVICE, "bad mem flag %d", mem);
+  if (B == 0) return EIOKU_OK;
+  EIOKU_REQUIRE(ids && mask && out, "NULL buffer");
+  for (const auto& t : m->tensors) EIOKU_REQUIRE(t.set, "tensor %s has no weights", t.name.c_str());
+  hipStream_t stream = (hipStream_t)stream_;
+  const int H = m->H, T = B * S;
+  int rc;
+  const int32_t* d_ids = ids;
+  const uint8_t* d_mask = mask;
+  float* d_out = out;
+  if (mem == EIOKU_MEM_HOST) {
+    for (int i = 0; i < T; ++i) EIOKU_REQUIRE(ids[i] >= 0 && ids[i] < m->vocab, "token id %d at %d outside the vocabulary", ids[i], i);
+    if ((rc = grow(&m->d_ids, &m->ids_cap, (size_t)T * 4))) return rc;
+    if ((rc = grow(&m->d_mask, &m->mask_cap, (size_t)T))) return rc;
+    if ((rc = grow(&m->d_out, &m->out_cap, (size_t)B * H * 4))) return rc;
+    EIOKU_HIP_CHECK(hipMemcpyAsync(m->d_ids, ids, (size_t)T * 4, hipMemcpyHostToDevice, stream));
+    EIOKU_HIP_CHECK(hipMemcpyAsync(m->d_mask, mask, (size_t)T, hipMemcpyHostToDevice, stream));
+    d_ids = m->d_ids;
+    d_mask = m->d_mask;
+    d_out = m->d_out;
+  }
+  if ((rc = grow(&m->x, &m->x_cap, (size_t)T * H * 4))) return rc;
+  if ((rc = grow(&m->y, &m->y_cap, (size_t)T * H * 4))) return rc;
+  if ((rc = grow(&m->ctx, &m->ctx_cap, (size_t)T * H * 4))) return rc;
+  if ((rc = grow(&m->qkv, &m->qkv_cap, (size_t)T * 3 * H * 4))) return rc;
+  if ((rc = grow(&m->mid, &m->mid_cap, (size_t)T * m->ffn * 4))) return rc;
+
+  const unsigned tok_blocks = (unsigned)(((size_t)T * 64 + 255) / 256);
+  hipLaunchKernelGGL(k_embed_ln, dim3(tok_blocks), dim3(256), 0, stream, d_ids, T, S, H, m->vocab,
+                     tp(m, "embeddings.word_embeddings.weight"), tp(m, "embeddings.position_embeddings.weight"),
+                     tp(m, "embeddings.token_type_embeddings.weight"), tp(m, "embeddings.LayerNorm.weight"),
+                     tp(m, "embeddings.LayerNorm.bias"), m->eps, m->x);
+  EIOKU_LAUNCH_CHECK();
+  const int athreads = ((S + 63) / 64) * 64;
+  const size_t alds = (size_t)S * 8 * 16 * 2 + (size_t)S * 4;
+  if (alds > 64 * 1024) {
+    static bool attr = false;
+    if (!attr) {
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+      attr = true;
+    }
+  }
+  for (int l = 0; l < m->L; ++l) {
+    const std::string p = "encoder.layer." + std::to_string(l) + ".";
+    if ((rc = gemm(m->x, H, tp(m, p + "attention.self.query.weight"), tp(m, p + "attention.self.query.bias"), m->qkv,
+                   3 * H, T, 3 * H, H, 0, stream))) return rc;
+    hipLaunchKernelGGL(k_attention, dim3(B, m->heads), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
+    EIOKU_LAUNCH_CHECK();
+    if ((rc = gemm(m->ctx, H, tp(m, p + "attention.output.dense.weight"), tp(m, p + "attention.output.dense.bias"), m->y,
+                   H, T, H, H, 0, stream))) return rc;
+    hipLaunchKernelGGL(k_add_ln, dim3(tok_blocks), dim3(256), 0, stream, m->y, m->x, T, H,
+                       tp(m, p + "attention.output.LayerNorm.weight"), tp(m, p + "attention.output.LayerNorm.bias"),
+                       m->eps, m->x);
+    EIOKU_LAUNCH_CHECK();
+    if ((rc = gemm(m->x, H, tp(m, p + "intermediate.dense.weight"), tp(m, p + "intermediate.dense.bias"), m->mid, m->ffn,
+                   T, m->ffn, H, 1, stream))) return rc;
+    if ((rc = gemm(m->mid, m->ffn, tp(m, p + "output.dense.weight"), tp(m, p + "output.dense.bias"), m->y, H, T, H,
+                   m->ffn, 0, stream))) return rc;
+    hipLaunchKernelGGL(k_add_ln, dim3(tok_blocks), dim3(256), 0, stream, m->y, m->x, T, H,
+                       tp(m, p + "output.LayerNorm.weight"), tp(m, p + "output.LayerNorm.bias"), m->eps, m->x);
+    EIOKU_LAUNCH_CHECK();
+  }
+  const int pthreads = ((H + 63) / 64) * 64;
+  hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(pthreads), 0, stream, m->x, d_mask, S, H, d_out);
+  EIOKU_LAUNCH_CHECK();
+  m->flops_last = (double)T * m->L * (2.0 * H * 3 * H + 2.0 * H * H + 4.0 * H * m->ffn) +
+                  (double)B * m->heads * m->L * 4.0 * S * S * 32;
+  if (mem == EIOKU_MEM_HOST) {
+    EIOKU_HIP_CHECK(hipMemcpyAsync(out, d_out, (size_t)B * H * 4, hipMemcpyDeviceToHost, stream));
+    EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return EIOKU_OK;
+}
+
+int eioku_bert_last_flops(const eioku_bert* m, double* flops) {
+  EIOKU_REQUIRE(m && flops, "NULL argument");
+  *flops = m->flops_last;
+  return EIOKU_OK;
+}
+
+}  // extern "C"

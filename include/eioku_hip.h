@@ -209,6 +209,26 @@ int eioku_index_search(eioku_index_t* ix, const float* q, int nq, int k, float* 
 int eioku_topk_merge(const float* d_lists, const int64_t* i_lists, int nlists, int nq, int k, float* D,
                      int64_t* I, void* stream);
 
+/* ---- segment embedding: all-MiniLM-L6-v2 (BERT encoder + mean pooling + L2 norm) ----------
+ * The reference holds intent only (.kiro/specs/semantic-video-search/design.md:54-57,1096-1103;
+ * tasks.md:297-302 unchecked); BASELINE.json's north_star names all-MiniLM-L6-v2: vocab 30522,
+ * hidden 384, 6 layers, 12 heads, ffn 1536, 512 positions, 2 token types, LayerNorm eps 1e-12.
+ * Tensors carry the Hugging Face BertModel state-dict names ("embeddings.word_embeddings.weight",
+ * "encoder.layer.0.attention.self.query.weight", ...), fp32, row-major [out][in].
+ * Tokenisation (WordPiece) stays on the host.  head_dim must be 32; hidden, ffn % 128 == 0.
+ */
+typedef struct eioku_bert eioku_bert_t;
+int eioku_bert_create(int vocab, int hidden, int layers, int heads, int ffn, int max_pos, int type_vocab,
+                      float ln_eps, eioku_bert_t** out);
+void eioku_bert_destroy(eioku_bert_t* m);
+int eioku_bert_num_tensors(const eioku_bert_t* m);
+int eioku_bert_tensor_info(const eioku_bert_t* m, int idx, char* name, size_t name_cap, int* rows, int* cols);
+int eioku_bert_set_tensor(eioku_bert_t* m, int idx, const float* host_data, size_t numel);
+/* ids int32 [B][S], mask uint8 [B][S] (1 = token) -> out float32 [B][hidden], unit L2 norm. */
+int eioku_bert_embed(eioku_bert_t* m, const int32_t* ids, const uint8_t* mask, int B, int S, float* out,
+                     int mem, void* stream);
+int eioku_bert_last_flops(const eioku_bert_t* m, double* flops);
+
 #ifdef __cplusplus
 }
 #endif

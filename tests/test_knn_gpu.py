@@ -138,7 +138,8 @@ def test_full_size_properties_1m(gpu):
         alli = torch.cat([best_i, ci + lo], 1)
         o = torch.argsort(alld, dim=1, stable=True)[:, :k]
         best_d, best_i = torch.gather(alld, 1, o), torch.gather(alli, 1, o)
-    assert torch.allclose(D.double(), best_d.clamp(min=0), rtol=RTOL, atol=1e-6)
+    err = (D.double() - best_d.clamp(min=0)).abs()
+    assert bool((err <= 1e-6 + RTOL * best_d.abs()).all()), float(err.max())
     assert (I == best_i).float().mean() > 0.995  # near-ties may swap within tolerance
     # shards
     dl, il = [], []
