@@ -1,0 +1,176 @@
+"""Frame sources for the drop-in ``ModelManager`` (the ``cv2.VideoCapture`` seam).
+
+The reference reads frames with ``cv2.VideoCapture(video_path)`` - ``get(CAP_PROP_FPS)``,
+``get(CAP_PROP_FRAME_COUNT)``, ``read()``, ``grab()``, ``release()``
+(``/root/reference/ml-service/src/services/model_manager.py:237-299``) - and scene detection shells
+out to ffmpeg.  Video *decode* is outside this round's scope, so this module
+only provides the same small surface over what is available:
+
+  * ``cv2`` itself when the deployment image has it (the reference's container does);
+  * ``.npy`` raw clips ``(n,h,w,3)`` uint8 BGR, memory mapped, with an optional ``<file>.json``
+    sidecar ``{"fps": 29.97, "time_base": [1001, 30000], "duration": 6.673}``;
+  * ``.y4m`` (YUV4MPEG2, 4:2:0 / 4:4:4 / mono, 8 bit) for the scene stage: exactly the luma plane the
+    ffmpeg ``select`` filter scores.
+"""
+
+from __future__ import annotations
+
+import json
+from fractions import Fraction
+from pathlib import Path
+
+import numpy as np
+
+
+class FrameSource:
+    """Minimal ``cv2.VideoCapture`` look-alike."""
+
+    fps: float = 30.0
+    total_frames: int = 0
+    time_base: tuple[int, int] = (1, 30)  # seconds per pts tick (vf_showinfo's pts_time = pts * tb)
+    duration_s: float | None = None
+
+    def read(self):  # -> (ok, frame_bgr)
+        raise NotImplementedError
+
+    def grab(self) -> bool:
+        raise NotImplementedError
+
+    def release(self) -> None:
+        pass
+
+    def luma_planes(self, start: int, count: int) -> np.ndarray:
+        """``(count,h,w)`` uint8 luma of frames [start, start+count) for the scene stage."""
+        raise NotImplementedError
+
+
+def _fps_to_time_base(fps: float) -> tuple[int, int]:
+    fr = Fraction(fps).limit_denominator(1001)
+    return fr.denominator, fr.numerator
+
+
+class NpyFrameSource(FrameSource):
+    def __init__(self, path):
+        self.path = Path(path)
+        self.frames = np.load(self.path, mmap_mode="r")
+        if self.frames.ndim != 4 or self.frames.shape[-1] != 3 or self.frames.dtype != np.uint8:
+            raise ValueError(f"{path}: expected (n,h,w,3) uint8 BGR frames")
+        meta = {}
+        side = Path(str(self.path) + ".json")
+        if side.exists():
+            meta = json.loads(side.read_text())
+        self.fps = float(meta.get("fps", 30.0))
+        self.total_frames = int(self.frames.shape[0])
+        self.time_base = tuple(meta.get("time_base", _fps_to_time_base(self.fps)))
+        self.duration_s = meta.get("duration", self.total_frames / self.fps if self.fps else None)
+        self.pos = 0
+
+    def read(self):
+        if self.pos >= self.total_frames:
+            return False, None
+        f = np.ascontiguousarray(self.frames[self.pos])
+        self.pos += 1
+        return True, f
+
+    def grab(self):
+        if self.pos >= self.total_frames:
+            return False
+        self.pos += 1
+        return True
+
+    def luma_planes(self, start, count):
+        # raw BGR has no Y plane; BT.601 studio-range integer luma stands in for the decoder's
+        f = self.frames[start:start + count].astype(np.int32)
+        y = ((66 * f[..., 2] + 129 * f[..., 1] + 25 * f[..., 0] + 128) >> 8) + 16
+        return y.astype(np.uint8)
+
+
+class Y4mSource(FrameSource):
+    """YUV4MPEG2 reader (8-bit C420*, C444, Cmono): luma plane access for the scene stage."""
+
+    def __init__(self, path):
+        self.path = Path(path)
+        with open(self.path, "rb") as f:
+            header = f.readline()
+        if not header.startswith(b"YUV4MPEG2"):
+            raise ValueError(f"{path}: not a YUV4MPEG2 file")
+        w = h = None
+        fr = Fraction(30, 1)
+        cs = "420"
+        for tok in header.split()[1:]:
+            t = tok.decode()
+            if t[0] == "W":
+                w = int(t[1:])
+            elif t[0] == "H":
+                h = int(t[1:])
+            elif t[0] == "F":
+                a, b = t[1:].split(":")
+                fr = Fraction(int(a), int(b))
+            elif t[0] == "C":
+                cs = t[1:]
+        if "p10" in cs or "p12" in cs or "p16" in cs:
+            raise ValueError("only 8-bit y4m is supported")
+        self.w, self.h = w, h
+        cw, chh = (w, h) if cs.startswith("444") else ((0, 0) if cs.startswith("mono") else ((w + 1) // 2, (h + 1) // 2))
+        self.frame_bytes = w * h + 2 * cw * chh
+        self.header_len = len(header)
+        size = self.path.stat().st_size
+        self.total_frames = (size - self.header_len) // (6 + self.frame_bytes)  # "FRAME\n" + payload
+        self.fps = float(fr)
+        self.time_base = (fr.denominator, fr.numerator)
+        self.duration_s = self.total_frames / self.fps
+        self.pos = 0
+        self._mm = np.memmap(self.path, dtype=np.uint8, mode="r")
+
+    def luma_planes(self, start, count):
+        out = np.empty((count, self.h, self.w), dtype=np.uint8)
+        for i in range(count):
+            off = self.header_len + (start + i) * (6 + self.frame_bytes) + 6
+            out[i] = self._mm[off:off + self.w * self.h].reshape(self.h, self.w)
+        return out
+
+    def grab(self):
+        if self.pos >= self.total_frames:
+            return False
+        self.pos += 1
+        return True
+
+    def read(self):
+        raise RuntimeError("y4m sources carry no BGR frames here; use them for scene detection")
+
+
+class Cv2FrameSource(FrameSource):
+    def __init__(self, path):
+        import cv2
+
+        self._cv2 = cv2
+        self.cap = cv2.VideoCapture(path)
+        self.fps = self.cap.get(cv2.CAP_PROP_FPS) or 30
+        self.total_frames = int(self.cap.get(cv2.CAP_PROP_FRAME_COUNT))
+        self.time_base = _fps_to_time_base(self.fps)
+        self.duration_s = self.total_frames / self.fps if self.fps else None
+
+    def read(self):
+        return self.cap.read()
+
+    def grab(self):
+        return self.cap.grab()
+
+    def release(self):
+        self.cap.release()
+
+    def luma_planes(self, start, count):
+        raise RuntimeError("decoded BGR has no decoder luma; the scene stage needs a .y4m / raw source")
+
+
+def open_video(path: str) -> FrameSource:
+    p = str(path)
+    if p.endswith(".npy"):
+        return NpyFrameSource(p)
+    if p.endswith(".y4m"):
+        return Y4mSource(p)
+    try:
+        return Cv2FrameSource(p)
+    except ImportError as e:
+        raise RuntimeError(f"cannot open {p!r}: no decoder available (cv2 not installed; raw .npy / .y4m clips are "
+                           "supported natively)") from e

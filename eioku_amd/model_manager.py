@@ -1,0 +1,286 @@
+"""Drop-in ``ModelManager`` for the ml-service worker: same methods, arguments, result dicts and
+error behaviour as ``/root/reference/ml-service/src/services/model_manager.py`` for the three task
+types on the hot path, with the arithmetic on the MI355X HIP library instead of
+ffmpeg / OpenCV / Ultralytics on the CPU.
+
+    detect_objects(video_path, config) -> {"detections": [{frame_index, timestamp_ms, label,
+                                           confidence, bbox{x,y,width,height}}]}       (ref :215-306)
+    detect_faces(video_path, config)   -> same + "cluster_id": None, label "face"      (ref :308-407)
+    detect_scenes(video_path, config)  -> {"scenes": [{scene_index, start_ms, end_ms,
+                                           duration_ms}]}                              (ref :715-835)
+
+What changes underneath (and nothing else): sampled frames are detected in batches instead of one
+``model(frame)`` call each, and the scene score is computed by K1/K2 instead of an ffmpeg child
+process.  Sampling rule, timestamps, label lookup, float widening and the scene-list quirks are the
+reference's (pinned by ``tests/golden/ref_detect_loop.json`` / ``ref_scenes.json``).
+
+There is no CPU fallback: without the HIP library / a gfx950 device the calls raise.
+"""
+
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+OUT_OF_SCOPE = "is outside the MI355X hot path (SURVEY.md §8): delegate to the reference ModelManager"
+
+
+class ModelManager:
+    """Manages model lifecycle and inference for the hot-path task types."""
+
+    def __init__(self, cache_dir: str = "/models", *, frame_source=None, detector_factory=None, batch_size: int = 64,
+                 random_init_seed: int | None = None):
+        """``cache_dir`` as in the reference (:12-21).  Keyword-only extras are seams for tests and bench:
+        ``frame_source(path) -> FrameSource``, ``detector_factory(model_name, cache_dir) -> detector`` with
+        ``detect(frames, conf=...) -> (dets, counts)`` and ``names``; ``random_init_seed`` builds random
+        weights of the right shapes when no checkpoint can exist (offline benchmarks)."""
+        self.cache_dir = Path(cache_dir)
+        self.cache_dir.mkdir(parents=True, exist_ok=True)
+        self.models = {}
+        self._gpu_available = None  # Lazy initialization
+        self._frame_source = frame_source
+        self._detector_factory = detector_factory
+        self._batch_size = int(batch_size)
+        self._seed = random_init_seed
+
+    # ---- GPU probe: identical surface to the reference (:23-42, 168-213) -------------------------
+    @property
+    def gpu_available(self) -> bool:
+        if self._gpu_available is None:
+            try:
+                import torch
+
+                self._gpu_available = torch.cuda.is_available()
+            except Exception as e:  # noqa: BLE001 - same tolerance as the reference
+                logger.warning(f"Could not check GPU availability: {e}")
+                self._gpu_available = False
+        return self._gpu_available
+
+    def _get_device(self) -> str:
+        return "cuda" if self.gpu_available else "cpu"  # ROCm torch reports through torch.cuda
+
+    def get_gpu_info(self) -> dict:
+        if not self.gpu_available:
+            return {"gpu_available": False, "gpu_device_name": None, "gpu_memory_total_mb": None,
+                    "gpu_memory_used_mb": None}
+        import torch
+
+        return {"gpu_available": True, "gpu_device_name": torch.cuda.get_device_name(0),
+                "gpu_memory_total_mb": int(torch.cuda.get_device_properties(0).total_memory / 1e6),
+                "gpu_memory_used_mb": int(torch.cuda.memory_allocated(0) / 1e6)}
+
+    def detect_gpu(self) -> bool:
+        return self.gpu_available
+
+    def log_gpu_info(self):
+        if self.gpu_available:
+            info = self.get_gpu_info()
+            logger.info(f"GPU device: {info['gpu_device_name']}")
+            logger.info(f"GPU memory: {info['gpu_memory_total_mb'] / 1e3:.2f} GB")
+        else:
+            logger.warning("GPU not available - the HIP hot path cannot run")
+
+    # ---- out-of-scope members: fail loudly, never silently diverge ----------------------------------
+    async def download_model(self, model_name: str, model_type: str):
+        raise NotImplementedError(f"download_model {OUT_OF_SCOPE} (needs network)")
+
+    async def verify_model(self, model_name: str, model_type: str) -> bool:
+        raise NotImplementedError(f"verify_model {OUT_OF_SCOPE}")
+
+    async def transcribe_video(self, video_path: str, config: dict) -> dict:
+        raise NotImplementedError(f"transcribe_video {OUT_OF_SCOPE}")
+
+    async def extract_ocr(self, video_path: str, config: dict) -> dict:
+        raise NotImplementedError(f"extract_ocr {OUT_OF_SCOPE}")
+
+    async def classify_places(self, video_path: str, config: dict) -> dict:
+        raise NotImplementedError(f"classify_places {OUT_OF_SCOPE}")
+
+    async def extract_metadata(self, video_path: str, config: dict) -> dict:
+        raise NotImplementedError(f"extract_metadata {OUT_OF_SCOPE}")
+
+    # ---- seams ----------------------------------------------------------------------------------------
+    def _open(self, video_path: str):
+        if self._frame_source is not None:
+            return self._frame_source(video_path)
+        from .frames import open_video
+
+        return open_video(video_path)
+
+    def _load_detector(self, model_name: str):
+        """``YOLO(cache_dir/ultralytics/model_name); model.to(device)`` (ref :252-254): per job, like the reference."""
+        if self._detector_factory is not None:
+            return self._detector_factory(model_name, self.cache_dir)
+        from .detect import Yolov8Detector
+
+        path = self.cache_dir / "ultralytics" / model_name
+        if self._seed is not None and not path.exists():
+            return Yolov8Detector.from_model_name(model_name, seed=self._seed)
+        return Yolov8Detector.from_model_name(model_name, path=path)
+
+    # ---- objects / faces: one skeleton, as in the reference --------------------------------------------
+    def _detect_loop(self, video_path: str, model_name: str, confidence_threshold: float,
+                     frame_interval_seconds: float, face: bool) -> list[dict]:
+        cap = self._open(video_path)
+        fps = cap.fps or 30
+        total_frames = int(cap.total_frames)
+        logger.info(f"Video FPS: {fps}, Total frames: {total_frames}")
+        frame_interval = max(1, int(fps * frame_interval_seconds))
+        frames_to_process = (total_frames + frame_interval - 1) // frame_interval
+        logger.info(f"Processing every {frame_interval} frames (every {frame_interval_seconds}s at {fps} FPS, "
+                    f"~{frames_to_process} frames to process)")
+        detector = self._load_detector(model_name)
+        names = detector.names
+
+        detections: list[dict] = []
+        pend_frames: list[np.ndarray] = []
+        pend_meta: list[tuple[int, int]] = []
+
+        def flush():
+            if not pend_frames:
+                return
+            batch = np.stack(pend_frames)
+            dets, counts = detector.detect(batch, conf=confidence_threshold)
+            for (frame_idx, timestamp_ms), row, cnt in zip(pend_meta, dets, counts):
+                for d in row[: int(cnt)]:
+                    x1, y1, x2, y2 = (np.float32(d[k]) for k in ("x1", "y1", "x2", "y2"))
+                    confidence = float(np.float32(d["conf"]))  # float32 -> Python float, as float(tensor)
+                    if face and confidence < confidence_threshold:
+                        continue  # the face path's extra safety filter (ref :375-377)
+                    det = {
+                        "frame_index": frame_idx,
+                        "timestamp_ms": timestamp_ms,
+                        "label": "face" if face else names[int(d["cls"])],
+                        "confidence": confidence,
+                        "bbox": {"x": float(x1), "y": float(y1),
+                                 "width": float(np.float32(x2 - x1)), "height": float(np.float32(y2 - y1))},
+                    }
+                    if face:
+                        det["cluster_id"] = None
+                    detections.append(det)
+            pend_frames.clear()
+            pend_meta.clear()
+
+        frame_idx = 0
+        try:
+            while True:
+                if frame_idx % frame_interval == 0:
+                    ret, frame = cap.read()
+                    if not ret:
+                        break
+                    pend_frames.append(frame)
+                    pend_meta.append((frame_idx, int((frame_idx / fps) * 1000)))
+                    if len(pend_frames) >= self._batch_size:
+                        flush()
+                else:
+                    if not cap.grab():
+                        break
+                frame_idx += 1
+            flush()
+        finally:
+            cap.release()
+            close = getattr(detector, "close", None)
+            if close:
+                close()
+        return detections
+
+    async def detect_objects(self, video_path: str, config: dict) -> dict:
+        """Detect objects in video using YOLOv8 on the HIP path (reference: :215-306)."""
+        try:
+            model_name = config.get("model_name", "yolov8n.pt")
+            confidence_threshold = config.get("confidence_threshold", 0.5)
+            frame_interval_seconds = config.get("frame_interval", 1)
+            logger.info(f"Object detection: {video_path} (device: {self._get_device()})")
+            detections = self._detect_loop(video_path, model_name, confidence_threshold, frame_interval_seconds, False)
+            logger.info(f"✅ Object detection complete: {len(detections)} detections")
+            return {"detections": detections}
+        except Exception as e:
+            logger.error(f"Object detection failed: {e}", exc_info=True)
+            raise
+
+    async def detect_faces(self, video_path: str, config: dict) -> dict:
+        """Detect faces in video using YOLOv8-face on the HIP path (reference: :308-407)."""
+        try:
+            model_name = config.get("model_name", "yolov8n-face.pt")
+            confidence_threshold = config.get("confidence_threshold", 0.7)
+            frame_interval_seconds = config.get("frame_interval", 3)
+            logger.info(f"Face detection: {video_path} (device: {self._get_device()})")
+            detections = self._detect_loop(video_path, model_name, confidence_threshold, frame_interval_seconds, True)
+            logger.info(f"✅ Face detection complete: {len(detections)} detections")
+            return {"detections": detections}
+        except Exception as e:
+            logger.error(f"Face detection failed: {e}", exc_info=True)
+            raise
+
+    # ---- scenes ----------------------------------------------------------------------------------------
+    async def detect_scenes(self, video_path: str, config: dict) -> dict:
+        """Scene boundaries.  Default = what the reference observes from
+        ``ffmpeg -vf select='gt(scene\\,T)',showinfo`` (:736-828): luma SAD score (K1), ``pts_time`` with
+        six significant digits, the scene list with its index quirk.  ``config["detector"] = "content"``
+        selects the PySceneDetect ContentDetector of BASELINE.json's north_star (K2) instead."""
+        try:
+            from . import scene
+
+            logger.info(f"Scene detection: {video_path}")
+            threshold = config.get("threshold", 0.7)
+            src = self._open(video_path)
+            try:
+                n = int(src.total_frames)
+                tb_num, tb_den = src.time_base
+                duration_ms = None if src.duration_s is None else int(float(src.duration_s) * 1000)
+                chunk = 64
+                if config.get("detector", "ffmpeg") == "content":
+                    sums = []
+                    prev = None
+                    for lo in range(0, n, chunk):
+                        frames = self._bgr_chunk(src, lo, min(chunk, n - lo))
+                        sums.append(scene.hsv_sums(frames, prev))
+                        prev = frames[-1]
+                    sums = np.concatenate(sums) if sums else np.zeros((0, 3), np.uint64)
+                    h, w = (frames.shape[1], frames.shape[2]) if n else (1, 1)
+                    scores = scene.content_scores(sums, h * w)
+                    cuts = scene.content_cuts(scores, float(config.get("content_threshold", 27.0)),
+                                              int(config.get("min_scene_len", 15)), config.get("filter_mode", "legacy"))
+                    ts = [0] + [int(float(scene.pts_time_string(c, tb_num, tb_den)) * 1000) for c in cuts]
+                    end = duration_ms if duration_ms is not None else (ts[-1] + 1000)
+                    scenes = [{"scene_index": i, "start_ms": a, "end_ms": b, "duration_ms": b - a}
+                              for i, (a, b) in enumerate(zip(ts, ts[1:] + [end]))]
+                    return {"scenes": scenes}
+                sad = []
+                prev = None
+                for lo in range(0, n, chunk):
+                    y = np.ascontiguousarray(src.luma_planes(lo, min(chunk, n - lo)))
+                    sad.append(scene.luma_sad(y, prev))
+                    prev = y[-1]
+                sad = np.concatenate(sad) if sad else np.zeros(0, np.uint64)
+                count = int(y.shape[1] * y.shape[2]) if n else 1
+                _, score = scene.ffmpeg_scene_scores(sad, count)
+                cut_ms = [int(float(scene.pts_time_string(int(c), tb_num, tb_den)) * 1000)
+                          for c in np.nonzero(score > float(threshold))[0]]
+                scenes = scene.build_scenes(cut_ms, duration_ms)
+                if len(cut_ms) == 0:
+                    logger.info(f"No scene cuts detected. Created single scene for entire video ({scenes[0]['end_ms']}ms)")
+                logger.info(f"✅ Scene detection complete: {len(scenes)} scenes")
+                return {"scenes": scenes}
+            finally:
+                src.release()
+        except Exception as e:
+            logger.error(f"Scene detection failed: {e}", exc_info=True)
+            raise
+
+    @staticmethod
+    def _bgr_chunk(src, lo, count):
+        frames = getattr(src, "frames", None)
+        if frames is not None:
+            return np.ascontiguousarray(frames[lo:lo + count])
+        out = []
+        for _ in range(count):
+            ok, f = src.read()
+            if not ok:
+                break
+            out.append(f)
+        return np.stack(out)

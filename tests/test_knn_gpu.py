@@ -139,7 +139,9 @@ def test_full_size_properties_1m(gpu):
         o = torch.argsort(alld, dim=1, stable=True)[:, :k]
         best_d, best_i = torch.gather(alld, 1, o), torch.gather(alli, 1, o)
     err = (D.double() - best_d.clamp(min=0)).abs()
-    assert bool((err <= 1e-6 + RTOL * best_d.abs()).all()), float(err.max())
+    # absolute floor: |q|^2 + |x|^2 - 2q.x cancels to a few ulps of 2.0 (as FAISS' BLAS path does) for the
+    # planted copies whose true distance is 0
+    assert bool((err <= 5e-6 + RTOL * best_d.abs()).all()), float(err.max())
     assert (I == best_i).float().mean() > 0.995  # near-ties may swap within tolerance
     # shards
     dl, il = [], []
