@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""Hot-path benchmark: frames/s through scene + detect + embed on synthetic frames resident in HBM.
+"""Hot-path benchmark: frames/s through scene + detect + embed on synthetic frames resident in HBM,
+plus kNN QPS@top-10 over 10M x 384 (BASELINE.json's two-part metric).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of synthetic input on every rank (weak
-scaling: videos shard one-per-GPU, no data-path collective - SURVEY.md 8e).  Rank 0 prints ONE JSON
-line.  `roofline` is the dominant kernel's algorithmic work / its HIP-event duration measured on the
-launch stream inside the timed region; `cpu_baseline` is the CPU oracle on a bounded sample (rank 0,
-N=1 only).  See DESIGN.md "Measurement" for the per-unit byte/flop figures.
+One "step" = one pass of the hot path over one batch of synthetic input on every rank: 64 BGR frames
+(BASELINE cfg2: 640x640) through scene scoring (K2 ContentDetector sums + K1 luma SAD), YOLOv8n
+detection (K3 letterbox, K4/K5 network, K6 decode, K7 NMS) and MiniLM embedding of 8 transcript
+segments x 128 tokens (K8; one segment per 8 frames is far denser than real speech).  Weak scaling:
+videos shard one-per-GPU, no data-path collective.  Rank 0 prints ONE JSON line.
+`roofline` is the dominant kernel's algorithmic work / its HIP-event duration measured on the launch
+stream inside the timed region; `cpu_baseline` is the CPU oracle on a bounded sample (rank 0, N=1).
+The kNN part runs after the timed frames region: rows sharded over ranks, replicated queries, one
+RCCL all-gather + local merge per search.  See DESIGN.md "Measurement".
 """
 from __future__ import annotations
 
@@ -38,7 +43,12 @@ def parse_args():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--model", default="yolov8n.pt")
     ap.add_argument("--conf", type=float, default=0.25)
-    ap.add_argument("--stages", default="scene,detect,embed", help="comma list (debug); default = all built stages")
+    ap.add_argument("--segments", type=int, default=8, help="transcript segments embedded per step")
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--stages", default="scene,detect,embed", help="comma list (debug)")
+    ap.add_argument("--knn-n", type=int, default=10_000_000, help="0 disables the kNN part")
+    ap.add_argument("--knn-nq", type=int, default=1024)
+    ap.add_argument("--knn-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU oracle sample budget")
     return ap.parse_args()
@@ -47,10 +57,12 @@ def parse_args():
 class Pipeline:
     """Each step consumes `batch` BGR frames already resident in HBM and leaves its results in HBM."""
 
-    BUILT = ("scene", "detect")  # stages that exist as HIP kernels; "embed" joins when K8 lands
+    BUILT = ("scene", "detect", "embed")
 
     def __init__(self, args, device, rank):
-        from eioku_amd import detect, synth
+        import torch
+
+        from eioku_amd import detect, embed, synth
 
         self.args = args
         self.device = device
@@ -64,10 +76,16 @@ class Pipeline:
         self.luma = [f[..., 1].contiguous() for f in self.frames]  # stands in for the decoder's Y plane
         self.prev = None
         self.det = None
+        self.enc = None
         if "detect" in self.stages:
             self.det = detect.Yolov8Detector.from_model_name(args.model, seed=7)  # random-init weights, exact shapes
             # a random net's logit scale is arbitrary: give it a trained detector's candidate density
             self.det.calibrate_random_head(self.frames[0][:8], frac=0.01, conf=args.conf)
+        if "embed" in self.stages:
+            self.enc = embed.MiniLMEncoder(embed.random_state(embed.MINILM_L6_V2, 11))
+            g = torch.Generator(device="cpu").manual_seed(11 + rank)
+            self.ids = torch.randint(1000, 30000, (args.segments, args.seq_len), generator=g, dtype=torch.int32).to(device)
+            self.mask = torch.ones((args.segments, args.seq_len), dtype=torch.uint8, device=device)
         self.last = None
 
     def step(self, i):
@@ -81,6 +99,8 @@ class Pipeline:
             self.prev = f[-1]
         if self.det is not None:
             out.append(self.det.detect(f, conf=self.args.conf, keep_on_device=True))
+        if self.enc is not None:
+            out.append(self.enc.encode_ids(self.ids, self.mask))
         self.last = out
 
     def dominant(self):
@@ -98,13 +118,64 @@ class Pipeline:
                 "alg_total": alg * cnt, "scale": 1e9, "ms_total": ms, "launches": cnt, "alg_per_step": alg}
 
 
+def knn_part(args, device, rank, world):
+    """kNN QPS@top-10 over knn_n x 384 (rows sharded over ranks, one all-gather per search)."""
+    import torch
+    import torch.distributed as dist
+
+    from eioku_amd import _lib, search, synth
+
+    d, k = 384, 10
+    lo, hi = search.shard_bounds(args.knn_n, world, rank)
+    xb = synth.normal_f32(21 + rank, hi - lo, d, device, l2_normalise=True)
+    q = synth.normal_f32(22, args.knn_nq, d, device, l2_normalise=True)  # same queries on every rank
+    ix = search.IndexFlatL2(d)
+    ix.attach(xb)
+    sh = search.ShardedFlatL2(ix, lo)
+    sh.search(q, k)  # warm-up (allocates workspaces)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.prof_enable(True)
+    _lib.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.knn_iters):
+        D, I = sh.search(q, k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms, cnt = _lib.prof_read(_lib.PROF_KNN)
+    per = dt / args.knn_iters
+    passes = (args.knn_nq + 31) // 32
+    alg_bytes = float(hi - lo) * d * 4 * passes  # SURVEY 8d: N*d*4 bytes per 32-query pass, this rank's shard
+    kernel_s = ms * 1e-3 / max(cnt, 1)
+    out = {"metric": f"kNN QPS@top-10 over {args.knn_n}x{d}", "value": args.knn_nq / per, "unit": "queries/s",
+           "nq": args.knn_nq, "k": k, "ms_per_search": per * 1e3, "n_total": args.knn_n, "rows_per_gpu": hi - lo,
+           "dtype": "f32", "collective": "none" if world == 1 else "all_gather_into_tensor (RCCL) of nq*k*16 B per rank",
+           "roofline": {"kernel": "k_flat_l2", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "achieved": alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0,
+                        "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS if kernel_s > 0 else 0.0,
+                        "avg_kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+                        "mfma_f32_tflops": 2.0 * args.knn_nq * (hi - lo) * d / kernel_s / 1e12 if kernel_s > 0 else 0.0}}
+    ix.close()
+    del xb
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(args, stages):
     """CPU oracle (numpy / torch-CPU port) on a bounded sample of the same workload: frames/s."""
     import numpy as np
     import torch
 
-    from eioku_amd import weights as W
-    from oracle import prng, scene as oscene, yolo as oy
+    from eioku_amd import embed, weights as W
+    from oracle import bert as obert, prng, scene as oscene, yolo as oy
 
     n = 2
     frames = prng.synth_frames_bgr(1234, n, args.height, args.width)
@@ -112,21 +183,32 @@ def cpu_baseline(args, stages):
     if "detect" in stages:
         variant, nc, _ = W.variant_from_model_name(args.model)
         net = oy.Net(W.random_state(variant, nc, 7), *W.YOLO_VARIANTS[variant], nc)
+    bert_state = embed.random_state(embed.MINILM_L6_V2, 11) if "embed" in stages else None
+    seg_per_frame = args.segments / args.batch
+    rng = np.random.default_rng(0)
     t0 = time.perf_counter()
     done = 0
+    seg_debt = 0.0
     while True:
         if "scene" in stages:
             oscene.content_sums(frames)
             oscene.luma_sad(np.ascontiguousarray(frames[..., 1]))
         if net is not None:
             oy.detect(net, frames, args.conf)
+        if bert_state is not None:
+            seg_debt += seg_per_frame * n
+            while seg_debt >= 1.0:  # same segments-per-frame ratio as the GPU step
+                ids = rng.integers(1000, 30000, (1, args.seq_len)).astype(np.int32)
+                obert.encode(bert_state, embed.MINILM_L6_V2, ids, np.ones_like(ids, dtype=np.uint8), dtype=np.float32)
+                seg_debt -= 1.0
         done += n
         if time.perf_counter() - t0 > args.cpu_seconds:
             break
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle stages {'+'.join(stages)} on {n} synthetic {args.height}x{args.width} frames per pass, "
-                      f"{done} frames in {dt:.1f}s; numpy (1 thread) + torch-CPU ({torch.get_num_threads()} threads)"}
+            "sample": f"oracle stages {'+'.join(stages)} on {n} synthetic {args.height}x{args.width} frames per pass "
+                      f"({seg_per_frame:.3f} segments/frame), {done} frames in {dt:.1f}s; numpy + torch-CPU "
+                      f"({torch.get_num_threads()} threads)"}
 
 
 def main():
@@ -177,7 +259,7 @@ def main():
     avg_ms = dom["ms_total"] / max(dom["launches"], 1)
     achieved = dom["alg_total"] / (dom["ms_total"] * 1e-3) / dom["scale"] if dom["ms_total"] > 0 else 0.0
     frames_total = args.batch * args.steps * world
-    note = "" if not pipe.missing else f"; NOT YET BUILT (value is not the full metric): {', '.join(pipe.missing)}"
+    note = "" if not pipe.missing else f"; stages NOT run (value is not the full metric): {', '.join(pipe.missing)}"
     out = {
         "metric": "frames/sec (scene+detect+embed) per node",
         "value": frames_total / elapsed,
@@ -191,16 +273,22 @@ def main():
         "vs_baseline": None,
         "dtype": "f16" if pipe.det is not None else "u8",
         "data": "synthetic",
-        "config": {"workload": f"{args.batch}x{args.height}x{args.width} BGR u8 frames/step/GPU resident in HBM, "
-                               f"{args.model} random-init; stages run: {', '.join(pipe.stages)}{note}",
+        "config": {"workload": f"{args.batch}x{args.height}x{args.width} BGR u8 frames/step/GPU resident in HBM: "
+                               f"scene (HSV ContentDetector sums + luma SAD) on every frame, {args.model} (random-init, "
+                               f"fp16) detect on every frame, all-MiniLM-L6-v2 (random-init, fp32) on {args.segments} "
+                               f"segments x {args.seq_len} tokens per step; stages run: {', '.join(pipe.stages)}{note}",
                    "batch": args.batch, "frame": [args.height, args.width], "parallelism": f"shard-by-video x{world}"},
         "roofline": {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": achieved, "peak": dom["peak"],
                      "unit": dom["unit"], "frac": achieved / dom["peak"], "traffic": None,
                      "avg_kernel_ms": avg_ms, "launches": dom["launches"], "kernel_ms_per_step": dom["ms_total"] / args.steps,
                      "algorithmic_per_step": dom["alg_per_step"]},
     }
+    if args.knn_n > 0:
+        del pipe
+        torch.cuda.empty_cache()
+        out["knn"] = knn_part(args, device, rank, world)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, pipe.stages)
+        out["cpu_baseline"] = cpu_baseline(args, [s for s in args.stages.split(",") if s in Pipeline.BUILT])
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
