@@ -96,49 +96,58 @@ __global__ __launch_bounds__(256) void k_add_ln(const float* __restrict__ a, con
 // ---------------------------------------------------------------------------------------------
 // GEMM: C[M][N] = A[M][K] . W[N][K]^T + bias[N]  (+ GELU).  N % 128 == 0, K % 32 == 0.
 // ---------------------------------------------------------------------------------------------
-constexpr int kBM = 128, kBN = 128, kBK = 32;
+constexpr int kBK = 32;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int EPI>  // 0: bias, 1: bias + GELU
+// BM x BN output tile per 4-wave workgroup (waves 2 x 2, each (BM/2) x (BN/2) = MI x NI MFMA tiles).
+// 128x128 for large M (MFMA-bound); 64x64 when M is small so that a batch of a few segments still
+// spreads over the chip instead of serialising K inside 24 workgroups.
+template <int EPI, int BM, int BN>  // EPI 0: bias, 1: bias + GELU
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ C, int ldc,
                                                      int M, int N, int K) {
-  __shared__ __attribute__((aligned(16))) float4 sA[2][kBM * 8];
-  __shared__ __attribute__((aligned(16))) float4 sW[2][kBN * 8];
+  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
+  constexpr int RA = BM / 32, RW = BN / 32;  // staged rows per thread
+  __shared__ __attribute__((aligned(16))) float4 sA[2][BM * 8];
+  __shared__ __attribute__((aligned(16))) float4 sW[2][BN * 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * kBM, n0 = blockIdx.y * kBN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int half = lane >> 5, l31 = lane & 31;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging map: 4 rows per thread, unit = tid & 7, rows (tid>>3) + 32*it
+  // staging map: unit = tid & 7, rows (tid>>3) + 32*it
   const int sunit = tid & 7, srow = tid >> 3;
-  float4 ra[4], rw[4];
+  float4 ra[RA], rw[RW];
   auto issue = [&](int kc) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = srow + 32 * it;
-      const int m = m0 + row;
+    for (int it = 0; it < RA; ++it) {
+      const int m = m0 + srow + 32 * it;
       ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M) ra[it] = *reinterpret_cast<const float4*>(A + (size_t)m * lda + kc * kBK + sunit * 4);
-      rw[it] = *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * K + kc * kBK + sunit * 4);
     }
+#pragma unroll
+    for (int it = 0; it < RW; ++it)
+      rw[it] = *reinterpret_cast<const float4*>(W + (size_t)(n0 + srow + 32 * it) * K + kc * kBK + sunit * 4);
   };
   auto commit = [&](int buf) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < RA; ++it) {
       const int row = srow + 32 * it;
-      const int pos = row * 8 + (sunit ^ ((row >> 1) & 7));
-      sA[buf][pos] = ra[it];
-      sW[buf][pos] = rw[it];
+      sA[buf][row * 8 + (sunit ^ ((row >> 1) & 7))] = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < RW; ++it) {
+      const int row = srow + 32 * it;
+      sW[buf][row * 8 + (sunit ^ ((row >> 1) & 7))] = rw[it];
     }
   };
 
@@ -151,21 +160,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
     if (kc + 1 < nk) issue(kc + 1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      float4 a[2], w[2];
+      float4 a[MI], w[NI];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + i * 32 + l31;
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm * WM + i * 32 + l31;
         a[i] = sA[buf][row * 8 + ((2 * t + half) ^ ((row >> 1) & 7))];
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = wn * 64 + j * 32 + l31;
+      for (int j = 0; j < NI; ++j) {
+        const int row = wn * WN + j * 32 + l31;
         w[j] = sW[buf][row * 8 + ((2 * t + half) ^ ((row >> 1) & 7))];
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NI; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, w[j].x, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, w[j].y, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, w[j].z, acc[i][j], 0, 0, 0);
@@ -177,14 +186,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
   }
   // epilogue: lane = column n, registers = rows m
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + l31;
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn * WN + j * 32 + l31;
     const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (m < M) {
           float v = acc[i][j][r] + bv;
           if (EPI == 1) v = gelu_erf(v);
@@ -196,11 +205,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
 }
 
 // ---------------------------------------------------------------------------------------------
-// attention: grid (B, heads), block = S threads rounded to 64 (S <= 512), head_dim == 32
-// qkv: [B*S][3H] with Q | K | V column blocks; ctx: [B*S][H]
+// attention: grid (B, heads), PARTS lanes per query (each owns the keys j = part mod PARTS), block =
+// PARTS*S threads rounded to 64, head_dim == 32.  qkv: [B*S][3H] = Q | K | V; ctx: [B*S][H]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_attention(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
-                                                   int S, int H, float* __restrict__ ctx) {
+template <int PARTS>
+__global__ __launch_bounds__(1024) void k_attention(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                    int S, int H, float* __restrict__ ctx) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float4* sK = reinterpret_cast<float4*>(sm);       // [S][8]
   float4* sV = sK + (size_t)S * 8;                  // [S][8]
@@ -215,10 +225,11 @@ __global__ __launch_bounds__(512) void k_attention(const float* __restrict__ qkv
   }
   for (int j = tid; j < S; j += blockDim.x) sM[j] = mask[row0 + j] ? 1.f : 0.f;
   __syncthreads();
-  if (tid >= S) return;
+  const int qi = tid / PARTS, part = tid % PARTS;
+  const bool live = qi < S;  // lanes of a query group stay together for the shuffles below
   float q[32];
   {
-    const float* qp = qkv + (row0 + tid) * (size_t)(3 * H) + h * 32;
+    const float* qp = qkv + (row0 + (live ? qi : 0)) * (size_t)(3 * H) + h * 32;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float4 v = *reinterpret_cast<const float4*>(qp + u * 4);
@@ -239,13 +250,15 @@ __global__ __launch_bounds__(512) void k_attention(const float* __restrict__ qkv
     return s / inv;
   };
   float mx = -INFINITY;
-  for (int j = 0; j < S; ++j)
+  for (int j = part; j < S; j += PARTS)
     if (sM[j] != 0.f) mx = fmaxf(mx, score(j));
+#pragma unroll
+  for (int off = 1; off < PARTS; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
   float acc[32];
 #pragma unroll
   for (int c = 0; c < 32; ++c) acc[c] = 0.f;
   float l = 0.f;
-  for (int j = 0; j < S; ++j) {
+  for (int j = part; j < S; j += PARTS) {
     if (sM[j] == 0.f) continue;
     const float e = expf(score(j) - mx);
     l += e;
@@ -258,7 +271,14 @@ __global__ __launch_bounds__(512) void k_attention(const float* __restrict__ qkv
       acc[u * 4 + 3] += e * v.w;
     }
   }
-  float* op = ctx + (row0 + tid) * (size_t)H + h * 32;
+#pragma unroll
+  for (int off = 1; off < PARTS; off <<= 1) {
+    l += __shfl_xor(l, off, 64);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
+  }
+  if (!live || part != 0) return;
+  float* op = ctx + (row0 + qi) * (size_t)H + h * 32;
   const float rl = l > 0.f ? 1.0f / l : 0.f;  // fully masked segment -> zeros (its pooled vector is 0 anyway)
 #pragma unroll
   for (int u = 0; u < 8; ++u)
@@ -272,6 +292,7 @@ __global__ __launch_bounds__(1024) void k_pool_norm(const float* __restrict__ x,
   __shared__ float red[16];
   const int b = blockIdx.x, c = threadIdx.x;
   float s = 0.f, cnt = 0.f;
+#pragma unroll 8
   for (int t = 0; t < S; ++t) {
     const float m = mask[(size_t)b * S + t] ? 1.f : 0.f;
     cnt += m;
@@ -344,11 +365,17 @@ const float* tp(const eioku_bert* m, const std::string& name) { return m->tensor
 
 int gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int epi,
          hipStream_t stream) {
-  EIOKU_REQUIRE(N % kBN == 0 && K % kBK == 0, "gemm shape N=%d K=%d must be multiples of 128 / 32", N, K);
-  dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)(N / kBN));
+  EIOKU_REQUIRE(N % 128 == 0 && K % kBK == 0, "gemm shape N=%d K=%d must be multiples of 128 / 32", N, K);
   prof_start(EIOKU_PROF_GEMM, stream);
-  if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
-  else hipLaunchKernelGGL((k_gemm_f32<0>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
+  if (M >= 8192) {
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)(N / 128));
+    if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
+    else hipLaunchKernelGGL((k_gemm_f32<0, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
+  } else {
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)(N / 64));
+    if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1, 64, 64>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
+    else hipLaunchKernelGGL((k_gemm_f32<0, 64, 64>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
+  }
   prof_stop(EIOKU_PROF_GEMM, stream);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
@@ -501,12 +528,13 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
                      tp(m, "embeddings.token_type_embeddings.weight"), tp(m, "embeddings.LayerNorm.weight"),
                      tp(m, "embeddings.LayerNorm.bias"), m->eps, m->x);
   EIOKU_LAUNCH_CHECK();
-  const int athreads = ((S + 63) / 64) * 64;
+  const int parts = S <= 256 ? 4 : 1;
+  const int athreads = ((S * parts + 63) / 64) * 64;
   const size_t alds = (size_t)S * 8 * 16 * 2 + (size_t)S * 4;
   if (alds > 64 * 1024) {
     static bool attr = false;
     if (!attr) {
-      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention),
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention<1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
       attr = true;
     }
@@ -515,7 +543,10 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
     const std::string p = "encoder.layer." + std::to_string(l) + ".";
     if ((rc = gemm(m->x, H, tp(m, p + "attention.self.query.weight"), tp(m, p + "attention.self.query.bias"), m->qkv,
                    3 * H, T, 3 * H, H, 0, stream))) return rc;
-    hipLaunchKernelGGL(k_attention, dim3(B, m->heads), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
+    if (parts == 4)
+      hipLaunchKernelGGL(k_attention<4>, dim3(B, m->heads), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
+    else
+      hipLaunchKernelGGL(k_attention<1>, dim3(B, m->heads), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
     EIOKU_LAUNCH_CHECK();
     if ((rc = gemm(m->ctx, H, tp(m, p + "attention.output.dense.weight"), tp(m, p + "attention.output.dense.bias"), m->y,
                    H, T, H, H, 0, stream))) return rc;

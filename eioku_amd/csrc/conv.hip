@@ -45,6 +45,118 @@ __device__ __forceinline__ float silu_f32(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
 
+// Epilogue for one accumulator fragment: the lane holds 4 consecutive couts c0..c0+3 of output pixel
+// `opix`: bias, SiLU, fp16 RNE, residual add (fp16(fp16(y) + x)), concat-slice store or fp32 store.
+// `b` = bias of c0..c0+3 and `rpre` = residual of (opix, c0..c0+3) are passed in registers when the
+// caller preloaded them (persistent kernels: a global load inside the tile loop would drain the
+// in-order vmcnt queue and with it the next tile's prefetch); have_rpre = false loads it here.
+__device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc, size_t opix, int c0, float4 b,
+                                           bool have_rpre = false, uint2 rpre = make_uint2(0, 0)) {
+  if (c0 >= a.Cout) return;
+  float v[4] = {acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w};
+  if (a.act == kActSiLU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = silu_f32(v[j]);
+  }
+  if (a.out_f32) {
+    float* o = a.out_f32 + opix * a.Cout + c0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j < a.Cout) o[j] = v[j];
+    return;
+  }
+  __half h[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h[j] = __float2half_rn(v[j]);
+  if (c0 + 3 < a.Cout) {
+    if (a.res) {
+      const uint2 r = have_rpre ? rpre : *reinterpret_cast<const uint2*>(a.res + opix * a.res_cs + c0);
+      const __half* rh = reinterpret_cast<const __half*>(&r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = __float2half_rn(__half2float(h[j]) + __half2float(rh[j]));
+    }
+    *reinterpret_cast<uint2*>(a.out + opix * a.out_cs + c0) = *reinterpret_cast<uint2*>(h);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j < a.Cout) {
+        __half o = h[j];
+        if (a.res) o = __float2half_rn(__half2float(o) + __half2float(a.res[opix * a.res_cs + c0 + j]));
+        a.out[opix * a.out_cs + c0 + j] = o;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 convolution = plain GEMM over pixels: a streaming kernel.  The weight tile (all of Cin x
+// 16*NF couts) sits in LDS for the whole launch; activations never touch LDS: every lane loads its
+// B fragment (16 pixels x 32 channels = 16 B per lane) straight from HBM, one k-step ahead of the
+// MFMAs, and waves walk the pixel groups grid-stride with no barrier in the loop.
+// ---------------------------------------------------------------------------------------------
+template <int NF>
+__global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* wt = reinterpret_cast<uint4*>(smem);  // [nchunks][16*NF][4 units], swizzled per row
+  constexpr int ROWS = 16 * NF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co_tile = blockIdx.y;
+  const uint4* wsrc = a.wgt + (size_t)co_tile * a.nchunks * (ROWS * 4);
+  for (int idx = tid; idx < a.nchunks * ROWS * 4; idx += 256) {
+    const int row = (idx >> 2) % ROWS, unit = idx & 3;
+    wt[(idx & ~3) + (unit ^ ((row >> 1) & 3))] = wsrc[idx];
+  }
+  __syncthreads();
+
+  const int r = lane & 15, u = lane >> 4;
+  const long long groups = (npix + 31) / 32;  // 32 pixels (2 fragments) per wave step
+  const long long gstride = (long long)gridDim.x * 4;
+  long long g = (long long)blockIdx.x * 4 + wave;
+
+  auto load_b = [&](long long grp, int kc, uint4 (&b)[2]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const long long p = grp * 32 + m * 16 + r;
+      const int c = kc * 32 + u * 8;
+      b[m] = make_uint4(0, 0, 0, 0);
+      if (p < npix && c < a.Cin) b[m] = *reinterpret_cast<const uint4*>(a.in + (size_t)p * a.in_cs + c);
+    }
+  };
+
+  float4 biasr[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) biasr[f] = *reinterpret_cast<const float4*>(a.bias + co_tile * ROWS + f * 16 + u * 4);
+  uint4 bn[2];
+  if (g < groups) load_b(g, 0, bn);
+  for (; g < groups; g += gstride) {
+    float4v acc[2][NF];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < a.nchunks; ++kc) {
+      uint4 b[2] = {bn[0], bn[1]};
+      if (kc + 1 < a.nchunks) load_b(g, kc + 1, bn);
+      else if (g + gstride < groups) load_b(g + gstride, 0, bn);  // next group's first step in flight
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int row = f * 16 + r;
+        uint4 w = wt[(kc * ROWS + row) * 4 + (u ^ ((row >> 1) & 3))];
+        half8 afrag = *reinterpret_cast<half8*>(&w);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, *reinterpret_cast<half8*>(&b[m]), acc[m][f], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const long long p = g * 32 + m * 16 + r;
+      if (p >= npix) continue;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) store_frag(a, acc[m][f], (size_t)p, co_tile * ROWS + f * 16 + u * 4, biasr[f]);
+    }
+  }
+}
+
 template <int NF, int KS, int S>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   constexpr int PH = (kTH - 1) * S + KS;
@@ -136,42 +248,204 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int c0 = co_tile * 16 * NF + f * 16 + (lane >> 4) * 4;
-      if (c0 >= a.Cout) continue;
-      const float4 b = *reinterpret_cast<const float4*>(a.bias + c0);
-      float v[4] = {acc[m][f][0] + b.x, acc[m][f][1] + b.y, acc[m][f][2] + b.z, acc[m][f][3] + b.w};
-      if (a.act == kActSiLU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = silu_f32(v[j]);
-      }
-      if (a.out_f32) {
-        float* o = a.out_f32 + opix * a.Cout + c0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (c0 + j < a.Cout) o[j] = v[j];
-        continue;
-      }
-      __half h[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) h[j] = __float2half_rn(v[j]);
-      if (c0 + 3 < a.Cout) {
-        if (a.res) {
-          const uint2 r = *reinterpret_cast<const uint2*>(a.res + opix * a.res_cs + c0);
-          const __half* rh = reinterpret_cast<const __half*>(&r);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) h[j] = __float2half_rn(__half2float(h[j]) + __half2float(rh[j]));
-        }
-        *reinterpret_cast<uint2*>(a.out + opix * a.out_cs + c0) = *reinterpret_cast<uint2*>(h);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (c0 + j < a.Cout) {
-            __half o = h[j];
-            if (a.res) o = __float2half_rn(__half2float(o) + __half2float(a.res[opix * a.res_cs + c0 + j]));
-            a.out[opix * a.out_cs + c0 + j] = o;
-          }
-      }
+      store_frag(a, acc[m][f], opix, c0, *reinterpret_cast<const float4*>(a.bias + c0));
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent 3x3 variant for the layers that dominate the pixel count (Cin <= 96): the whole weight
+// block of the cout tile (NCH chunks x 9 taps) stays in LDS for the launch, workgroups walk the
+// output tiles grid-stride, and the NEXT tile's halo patch is already in flight (registers) while the
+// current one is multiplied: one barrier per tile, HBM latency hidden behind the MFMAs.
+// ---------------------------------------------------------------------------------------------
+template <int NF, int S, int NCH, bool DB>
+__global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_tiles) {
+  constexpr int KS = 3, TAPS = 9, PAD = 1;
+  constexpr int PH = (kTH - 1) * S + KS;
+  constexpr int PW = (kTW - 1) * S + KS;
+  constexpr int PWH = (PW + 1) / 2;
+  constexpr int PWS = (S == 2) ? 2 * PWH : PW;
+  constexpr int PATCH_U = PH * PWS * 4;           // per chunk
+  constexpr int WT_U = TAPS * 16 * NF * 4;        // per chunk
+  constexpr int NLOAD = PH * PW * 4 * NCH;        // staged units per tile
+  constexpr int R = (NLOAD + 255) / 256;          // per thread
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* wt = reinterpret_cast<uint4*>(smem);                 // [NCH][WT_U]
+  uint4* patch = wt + NCH * WT_U;                             // [DB ? 2 : 1][NCH][PATCH_U]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co_tile = blockIdx.y;
+  {
+    const uint4* wsrc = a.wgt + (size_t)co_tile * NCH * WT_U;
+    for (int idx = tid; idx < NCH * WT_U; idx += 256) {
+      const int row = (idx % WT_U) >> 2, unit = idx & 3;
+      wt[(idx & ~3) + (unit ^ ((row >> 1) & 3))] = wsrc[idx];
+    }
+  }
+  // per-thread staging slots: slot j -> (chunk, pixel, unit) is tile independent
+  int s_off[R];      // LDS unit index inside one patch buffer, or -1
+  int s_py[R], s_px[R], s_c[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int idx = tid + 256 * j;
+    s_off[j] = -1;
+    s_py[j] = s_px[j] = s_c[j] = 0;
+    if (idx < NLOAD) {
+      const int cc = idx / (PH * PW * 4), rem = idx - cc * (PH * PW * 4);
+      const int pix = rem >> 2, unit = rem & 3;
+      const int py = pix / PW, px = pix - py * PW;
+      const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
+      const int p = py * PWS + col;
+      s_off[j] = cc * PATCH_U + p * 4 + (unit ^ ((p >> 1) & 3));
+      s_py[j] = py;
+      s_px[j] = px;
+      s_c[j] = cc * 32 + unit * 8;
+    }
+  }
+  const int tiles_per_img = a.tiles_w * a.tiles_h;
+  uint4 stage[R];
+  auto issue = [&](int tile) {
+    const int n = tile / tiles_per_img, t2 = tile - n * tiles_per_img;
+    const int th = t2 / a.tiles_w, tw = t2 - th * a.tiles_w;
+    const int ih0 = th * kTH * S - PAD, iw0 = tw * kTW * S - PAD;
+    const __half* in_n = a.in + (size_t)n * a.H * a.W * a.in_cs;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int ih = ih0 + s_py[j], iw = iw0 + s_px[j];
+      stage[j] = make_uint4(0, 0, 0, 0);
+      if (s_off[j] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W && s_c[j] < a.Cin)
+        stage[j] = *reinterpret_cast<const uint4*>(in_n + ((size_t)ih * a.W + iw) * a.in_cs + s_c[j]);
+    }
+  };
+
+  float4 biasr[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+    biasr[f] = *reinterpret_cast<const float4*>(a.bias + co_tile * 16 * NF + f * 16 + (lane >> 4) * 4);
+  const bool res_vec = a.res != nullptr && a.Cout >= 4;  // vector residual path (slices are 4-channel aligned)
+
+  int tile = blockIdx.x;
+  if (tile < total_tiles) issue(tile);
+  int buf = 0;
+  for (; tile < total_tiles; tile += gridDim.x) {
+    uint4* pb = patch + (DB ? buf : 0) * (NCH * PATCH_U);
+    if (!DB) __syncthreads();  // single buffer: every wave is done reading the previous tile
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      if (s_off[j] >= 0) pb[s_off[j]] = stage[j];
+    __syncthreads();  // also orders the weight copy before the first tile
+    const int tn = tile / tiles_per_img, tt2 = tile - tn * tiles_per_img;
+    const int tth = tt2 / a.tiles_w, ttw = tt2 - tth * a.tiles_w;
+    const int ow = ttw * kTW + (lane & 15);
+    // residual of THIS tile first, then the next tile's patch: the epilogue then waits only for the
+    // older loads (vmcnt is in order) and the prefetch stays in flight across it
+    uint2 resv[2][NF];
+    if (res_vec) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int oh = tth * kTH + wave * 2 + m;
+        const bool ok = oh < a.Ho && ow < a.Wo;
+        const size_t opix = ((size_t)tn * a.Ho + (ok ? oh : 0)) * a.Wo + (ok ? ow : 0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const int c0 = co_tile * 16 * NF + f * 16 + (lane >> 4) * 4;
+          resv[m][f] = make_uint2(0, 0);
+          if (ok && c0 + 3 < a.Cout) resv[m][f] = *reinterpret_cast<const uint2*>(a.res + opix * a.res_cs + c0);
+        }
+      }
+    }
+    const int next = tile + gridDim.x;
+    if (next < total_tiles) issue(next);  // in flight during the MFMAs below
+
+    float4v acc[2][NF];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) {
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int kh = tap / KS, kw = tap % KS;
+        half8 bfrag[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int py = (wave * 2 + m) * S + kh;
+          const int px = (lane & 15) * S + kw;
+          const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
+          const int p = py * PWS + col;
+          uint4 u = pb[cc * PATCH_U + p * 4 + ((lane >> 4) ^ ((p >> 1) & 3))];
+          bfrag[m] = *reinterpret_cast<half8*>(&u);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const int row = tap * 16 * NF + f * 16 + (lane & 15);
+          uint4 u = wt[cc * WT_U + row * 4 + ((lane >> 4) ^ ((row >> 1) & 3))];
+          half8 afrag = *reinterpret_cast<half8*>(&u);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag[m], acc[m][f], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int oh = tth * kTH + wave * 2 + m;
+      if (oh >= a.Ho || ow >= a.Wo) continue;
+      const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+        store_frag(a, acc[m][f], opix, co_tile * 16 * NF + f * 16 + (lane >> 4) * 4, biasr[f], res_vec, resv[m][f]);
+    }
+    buf ^= 1;
+  }
+}
+
+template <int NF, int S, int NCH, bool DB>
+int launch_persist(const ConvArgs& a, int ntiles, hipStream_t stream) {
+  constexpr int PH = (kTH - 1) * S + 3, PW = (kTW - 1) * S + 3;
+  constexpr int PWS = (S == 2) ? 2 * ((PW + 1) / 2) : PW;
+  constexpr size_t lds = ((size_t)NCH * 9 * 16 * NF * 4 + (DB ? 2 : 1) * (size_t)NCH * PH * PWS * 4) * 16;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_persist<NF, S, NCH, DB>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int total = a.tiles_w * a.tiles_h * a.N;
+  int per_cu = (int)(150 * 1024 / lds);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 4) per_cu = 4;
+  int bx = num_cus() * per_cu / ntiles;
+  if (bx < 1) bx = 1;
+  if (bx > total) bx = total;
+  hipLaunchKernelGGL((k_conv3x3_persist<NF, S, NCH, DB>), dim3((unsigned)bx, (unsigned)ntiles), dim3(256), lds, stream,
+                     a, total);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+// LDS bytes of the persistent variant
+size_t persist_lds(int nf, int s, int nch, bool db) {
+  const int ph = (kTH - 1) * s + 3, pw = (kTW - 1) * s + 3;
+  const int pws = s == 2 ? 2 * ((pw + 1) / 2) : pw;
+  return ((size_t)nch * 9 * 16 * nf * 4 + (db ? 2 : 1) * (size_t)nch * ph * pws * 4) * 16;
+}
+
+template <int S>
+int launch_persist_dispatch(int nf, int nch, bool db, const ConvArgs& a, int ntiles, hipStream_t stream, bool* handled) {
+  *handled = true;
+#define EIOKU_P(NF_, NCH_)                                                                    \
+  if (nf == NF_ && nch == NCH_)                                                                \
+    return db ? launch_persist<NF_, S, NCH_, true>(a, ntiles, stream) : launch_persist<NF_, S, NCH_, false>(a, ntiles, stream);
+  EIOKU_P(1, 1) EIOKU_P(2, 1) EIOKU_P(3, 1) EIOKU_P(4, 1) EIOKU_P(5, 1) EIOKU_P(6, 1)
+  EIOKU_P(1, 2) EIOKU_P(2, 2) EIOKU_P(3, 2) EIOKU_P(4, 2) EIOKU_P(5, 2)
+  EIOKU_P(1, 3) EIOKU_P(2, 3) EIOKU_P(3, 3) EIOKU_P(4, 3) EIOKU_P(5, 3)
+#undef EIOKU_P
+  *handled = false;
+  return EIOKU_OK;
 }
 
 template <int NF, int KS, int S>
@@ -207,13 +481,56 @@ int launch_nf(int nf, const ConvArgs& a, int ntiles, hipStream_t stream) {
   return EIOKU_EINVAL;
 }
 
+template <int NF>
+int launch1x1(const ConvArgs& a, int ntiles, hipStream_t stream) {
+  const size_t lds = (size_t)a.nchunks * 16 * NF * 64;
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv1x1<NF>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  const long long npix = (long long)a.N * a.H * a.W;
+  const long long groups = (npix + 31) / 32;
+  long long bx = (groups + 3) / 4;
+  const long long cap = (long long)num_cus() * 8;  // grid-stride beyond ~8 workgroups per CU
+  if (bx > cap) bx = cap;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL((k_conv1x1<NF>), dim3((unsigned)bx, (unsigned)ntiles), dim3(256), lds, stream, a, npix);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+int launch1x1_nf(int nf, const ConvArgs& a, int ntiles, hipStream_t stream) {
+  switch (nf) {
+    case 1: return launch1x1<1>(a, ntiles, stream);
+    case 2: return launch1x1<2>(a, ntiles, stream);
+    case 3: return launch1x1<3>(a, ntiles, stream);
+    case 4: return launch1x1<4>(a, ntiles, stream);
+    case 5: return launch1x1<5>(a, ntiles, stream);
+    case 6: return launch1x1<6>(a, ntiles, stream);
+    case 8: return launch1x1<8>(a, ntiles, stream);
+  }
+  set_error("unsupported nf %d", nf);
+  return EIOKU_EINVAL;
+}
+
 // Fewest padded channels first, then the widest tile (fewer re-reads of the input patch).
-int pick_nf(int cout, int ks) {
+int pick_nf(int cout, int ks, int nchunks, int stride) {
   const int frags = (cout + 15) / 16;
+  if (ks == 3 && nchunks <= 3) {
+    // persistent kernel: largest tile (<= 4 fragments, no padding waste beyond one fragment) that still fits
+    // two workgroups per CU with a single-buffered patch; otherwise fall through to the generic rule
+    for (int nf : {4, 3, 2, 1}) {
+      const int waste = ((frags + nf - 1) / nf) * nf - frags;
+      if (waste <= (frags >= 4 ? 1 : 0) && persist_lds(nf, stride, nchunks, false) <= 75 * 1024) return nf;
+    }
+  }
   const int cands[] = {8, 6, 5, 4, 3, 2, 1};
   int best = 1, best_waste = 1 << 30;
   for (int nf : cands) {
     if (ks == 3 && nf > 6) continue;  // LDS: 9 taps x 16*NF x 64 B
+    if (ks == 1 && nf * nchunks > 96) continue;  // 1x1: the whole Cin x tile weight block lives in LDS (<= 96 KB)
     int waste = ((frags + nf - 1) / nf) * nf - frags;
     if (waste < best_waste) {
       best_waste = waste;
@@ -235,10 +552,10 @@ int conv_weights_create(ConvWeights* cw, int cout, int cin, int ks, int stride, 
   cw->cin = cin;
   cw->ks = ks;
   cw->stride = stride;
-  cw->nf = pick_nf(cout, ks);
+  cw->nchunks = (cin + 31) / 32;
+  cw->nf = pick_nf(cout, ks, cw->nchunks, stride);
   const int tile = 16 * cw->nf;
   cw->ntiles = (cout + tile - 1) / tile;
-  cw->nchunks = (cin + 31) / 32;
   const int taps = ks * ks;
   const size_t wn = (size_t)cw->ntiles * cw->nchunks * taps * tile * 32;
   std::vector<_Float16> pw(wn, (_Float16)0.f);
@@ -302,10 +619,19 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
   a.nchunks = cw.nchunks;
   a.act = act;
   prof_start(EIOKU_PROF_CONV, stream);
-  int rc;
-  if (cw.ks == 3 && cw.stride == 1) rc = launch_nf<3, 1>(cw.nf, a, cw.ntiles, stream);
+  int rc = EIOKU_OK;
+  bool handled = false;
+  if (cw.ks == 3 && cw.nchunks <= 3) {
+    // double-buffer the patch only when that still leaves two workgroups per CU
+    const bool db = persist_lds(cw.nf, cw.stride, cw.nchunks, true) <= 75 * 1024;
+    if (persist_lds(cw.nf, cw.stride, cw.nchunks, db) <= 150 * 1024)
+      rc = cw.stride == 1 ? launch_persist_dispatch<1>(cw.nf, cw.nchunks, db, a, cw.ntiles, stream, &handled)
+                          : launch_persist_dispatch<2>(cw.nf, cw.nchunks, db, a, cw.ntiles, stream, &handled);
+  }
+  if (handled) {
+  } else if (cw.ks == 3 && cw.stride == 1) rc = launch_nf<3, 1>(cw.nf, a, cw.ntiles, stream);
   else if (cw.ks == 3 && cw.stride == 2) rc = launch_nf<3, 2>(cw.nf, a, cw.ntiles, stream);
-  else rc = launch_nf<1, 1>(cw.nf, a, cw.ntiles, stream);
+  else rc = launch1x1_nf(cw.nf, a, cw.ntiles, stream);
   prof_stop(EIOKU_PROF_CONV, stream);
   return rc;
 }
