@@ -27,9 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kQT = 32;        // queries per wave tile (MFMA N)
 constexpr int kRT = 32;        // database rows per MFMA tile (MFMA M)
-constexpr int kKC = 64;        // dims per LDS chunk (256 B per row)
 constexpr int kWaves = 4;
-constexpr int kMaxD = 512;     // register budget: d/2 VGPRs hold the query tile
 
 template <int K>
 struct TopK {
@@ -42,25 +40,23 @@ struct TopK {
       id[p] = 0x7FFFFFFF;
     }
   }
-  // keep ascending by (value, id); called only when (x, i) beats the tail
+  // Keep ascending by value.  A lane meets its rows in increasing id order, so on equal values the
+  // element already in the list has the smaller id and stays ahead: strict compares on the value alone
+  // give the (value, id) order without touching the ids (the merges across lanes do compare ids).
   __device__ __forceinline__ void insert(float x, int i) {
 #pragma unroll
     for (int p = K - 1; p > 0; --p) {
-      const bool shift = (v[p - 1] > x) || (v[p - 1] == x && id[p - 1] > i);
-      const bool here = !shift && ((v[p] > x) || (v[p] == x && id[p] > i));
-      const float nv = shift ? v[p - 1] : (here ? x : v[p]);
-      const int ni = shift ? id[p - 1] : (here ? i : id[p]);
-      v[p] = nv;
-      id[p] = ni;
+      const bool shift = v[p - 1] > x;
+      const bool here = !shift && (v[p] > x);
+      v[p] = shift ? v[p - 1] : (here ? x : v[p]);
+      id[p] = shift ? id[p - 1] : (here ? i : id[p]);
     }
-    if ((v[0] > x) || (v[0] == x && id[0] > i)) {
+    if (v[0] > x) {
       v[0] = x;
       id[0] = i;
     }
   }
-  __device__ __forceinline__ bool beats_tail(float x, int i) const {
-    return (x < v[K - 1]) || (x == v[K - 1] && i < id[K - 1]);
-  }
+  __device__ __forceinline__ bool beats_tail(float x, int) const { return x < v[K - 1]; }
 };
 
 struct KnnArgs {
@@ -76,20 +72,34 @@ struct KnnArgs {
   long long id_base;         // added to row ids at the very end (kept in merge)
 };
 
-// D = 32 x d query tile in registers, DB streamed through LDS.  grid = (db slabs, query tiles).
-template <int K, int D>
+// Query tile (32 x d) in registers, DB streamed through LDS.
+//   narrow (WIDE = false, nq <= 32): grid.y = query tiles; the 4 waves of a workgroup share the queries
+//     and split the slab's row tiles; each wave stages its own rows (wave-private LDS, no barriers).
+//   wide (WIDE = true): grid.y = groups of 4 query tiles; wave w owns query tile 4*blockIdx.y + w and
+//     all 4 waves multiply the SAME staged row tile, so the database is read from HBM once per 128
+//     queries instead of once per 32.
+// The (row tile, chunk) sequence is flat: the next chunk - also the first chunk of the next row tile -
+// is in flight (registers) while the current one is multiplied; row norms ride along with chunk 0 so
+// the epilogue issues no global load that would drain the in-order vmcnt queue.
+template <int K, int D, bool WIDE>
 __global__ __launch_bounds__(256, 1) void k_flat_l2(KnnArgs a) {
-  constexpr int NCH = D / kKC;          // chunks per row
-  constexpr int UPR = kKC / 4;          // 16-byte units per row chunk (16)
-  // 64 KB: four wave-private double buffers while streaming; reused for the final list merge
-  __shared__ __attribute__((aligned(16))) float4 lds[kWaves * 2 * kRT * UPR];
-  static_assert(sizeof(float) * 2 * kQT * kWaves * 2 * K <= sizeof(float4) * kWaves * 2 * kRT * UPR, "merge area");
-  float (*s_mv)[kWaves * 2][K] = reinterpret_cast<float (*)[kWaves * 2][K]>(lds);
-  int (*s_mi)[kWaves * 2][K] = reinterpret_cast<int (*)[kWaves * 2][K]>(reinterpret_cast<float*>(lds) + kQT * kWaves * 2 * K);
+  constexpr int KC = D < 128 ? D : 128;  // dims per LDS chunk (<= 512 B per row)
+  constexpr int NCH = D / KC;            // chunks per row
+  constexpr int UPR = KC / 4;          // 16-byte units per row chunk
+  constexpr int TILE_U = kRT * UPR;     // units per staged chunk
+  constexpr int NBUF = WIDE ? 1 : kWaves;
+  constexpr int SPT = WIDE ? TILE_U / 256 : TILE_U / 64;  // staged units per thread
+  constexpr int LISTS = WIDE ? 2 : 2 * kWaves;            // sorted lists per query to merge in the workgroup
+  constexpr int NQ_WG = WIDE ? kQT * kWaves : kQT;        // queries per workgroup
+  constexpr size_t STAGE_B = (size_t)NBUF * 2 * TILE_U * 16 + (size_t)NBUF * 2 * kRT * 4;
+  constexpr size_t MERGE_B = (size_t)NQ_WG * LISTS * K * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_B > MERGE_B ? STAGE_B : MERGE_B];
+  float4* lds = reinterpret_cast<float4*>(smem);
+  float* lnorm = reinterpret_cast<float*>(smem + (size_t)NBUF * 2 * TILE_U * 16);  // [NBUF][2][kRT]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
-  const int qt = blockIdx.y;
+  const int qt = WIDE ? blockIdx.y * kWaves + wave : blockIdx.y;
   const int qi = qt * kQT + col;
   const bool qvalid = qi < a.nq;
 
@@ -110,87 +120,136 @@ __global__ __launch_bounds__(256, 1) void k_flat_l2(KnnArgs a) {
 
   const long long slab0 = (long long)blockIdx.x * a.rows_per_block;
   const long long slab1 = min(a.n, slab0 + a.rows_per_block);
-  float4* my = lds + wave * (2 * kRT * UPR);
+  float4* my = lds + (WIDE ? 0 : wave) * (2 * TILE_U);
+  float* mynorm = lnorm + (WIDE ? 0 : wave) * (2 * kRT);
+  const int sid = WIDE ? tid : lane;            // staging id inside the staging group
+  const int sgroup = WIDE ? 256 : 64;
+  const long long tile_step = WIDE ? kRT : (long long)kRT * kWaves;
+  const long long first = slab0 + (WIDE ? 0 : (long long)wave * kRT);
 
-  // staging map: lane -> (row = it*4 + (lane>>4), unit = lane&15), 8 loads cover 32 rows x 256 B
-  const int srow = lane >> 4, sunit = lane & 15;
-  float4 stage[8];
-
+  float4 stage[SPT];
+  float stage_n = 0.f;
   auto issue = [&](long long row0, int ch) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const long long r = row0 + it * 4 + srow;
+    for (int it = 0; it < SPT; ++it) {
+      const int id = sid + sgroup * it;
+      const long long r = row0 + (id / UPR);
       stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < slab1) stage[it] = *reinterpret_cast<const float4*>(a.db + (size_t)r * D + ch * kKC + sunit * 4);
+      if (r < slab1) stage[it] = *reinterpret_cast<const float4*>(a.db + (size_t)r * D + ch * KC + (id % UPR) * 4);
+    }
+    if (ch == 0) {
+      stage_n = 0.f;
+      if (sid < kRT && row0 + sid < slab1) stage_n = a.dbnorm[row0 + sid];
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, int ch, int nbuf) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 4 + srow;
-      my[buf * (kRT * UPR) + row * UPR + (sunit ^ (row & 15))] = stage[it];
+    for (int it = 0; it < SPT; ++it) {
+      const int id = sid + sgroup * it;
+      const int row = id / UPR;
+      my[buf * TILE_U + row * UPR + ((id % UPR) ^ (row & 15))] = stage[it];
     }
-    // other lanes of this wave read these bytes: keep the compiler from moving LDS ops across
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (ch == 0 && sid < kRT) mynorm[nbuf * kRT + sid] = stage_n;
+  };
+  auto sync = [&]() {
+    if (WIDE) {
+      __syncthreads();
+    } else {  // wave-private buffers: LDS ops of one wave complete in order; only pin the compiler
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   };
 
-  // each wave walks its own row tiles: wave w takes tiles w, w+4, ... of the slab
-  for (long long row0 = slab0 + (long long)wave * kRT; row0 < slab1; row0 += (long long)kRT * kWaves) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // flat (tile, chunk) walk
+  long long row0 = first;
+  int buf = 0, nbuf = 0;  // data buffer / norm buffer parity
+  if (row0 < slab1) {
     issue(row0, 0);
-    commit(0);
+    commit(0, 0, 0);
+  }
+  sync();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  while (row0 < slab1) {
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      const int buf = ch & 1;
-      if (ch + 1 < NCH) issue(row0, ch + 1);  // next chunk in flight during the MFMAs below
-      // wave-private buffer: LDS operations of one wave complete in order, no barrier needed
+      const bool last = ch == NCH - 1;
+      const long long nrow = last ? row0 + tile_step : row0;
+      const int nch = last ? 0 : ch + 1;
+      const bool more = nrow < slab1;
+      if (more) issue(nrow, nch);  // in flight during the MFMAs below
+      // all LDS fragment reads of the chunk are issued before its MFMAs (counted lgkmcnt waits): a
+      // wave alone on its SIMD has nobody to hide a read-then-use latency behind
+      float4 xs[KC / 8];
 #pragma unroll
-      for (int t = 0; t < kKC / 8; ++t) {
-        const int row = col;  // A row index = lane & 31
-        const float4 x = my[buf * (kRT * UPR) + row * UPR + ((2 * t + half) ^ (row & 15))];
-        const float4 qq = Q[ch * (kKC / 8) + t];
+      for (int t = 0; t < KC / 8; ++t) xs[t] = my[buf * TILE_U + col * UPR + ((2 * t + half) ^ (col & 15))];
+#pragma unroll
+      for (int t = 0; t < KC / 8; ++t) {
+        const float4 x = xs[t];
+        const float4 qq = Q[ch * (KC / 8) + t];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, qq.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, qq.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, qq.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, qq.w, acc, 0, 0, 0);
       }
-      if (ch + 1 < NCH) commit(buf ^ 1);
-    }
-    // ---- distances + per-lane top-K: lane = query col, rows (r&3) + 8*(r>>2) + 4*half ----
+      // pin the issue order: 2 reads ahead, then 4 MFMAs per further read (hipcc otherwise sinks every read
+      // to just before its first MFMA and waits lgkmcnt(0) on it)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (row < slab1) {
-        float dist = (qn + a.dbnorm[row]) - 2.0f * acc[r];
-        dist = dist < 0.f ? 0.f : dist;
-        const int id = (int)(row - slab0);  // slab-local, fits 31 bits
-        if (top.beats_tail(dist, id)) top.insert(dist, id);
+      for (int t = 0; t < KC / 8; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
+      if (last) {
+        // ---- distances + per-lane top-K: lane = query col, rows (r&3) + 8*(r>>2) + 4*half ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const long long row = row0 + lr;
+          if (row < slab1) {
+            float dist = (qn + mynorm[nbuf * kRT + lr]) - 2.0f * acc[r];
+            dist = dist < 0.f ? 0.f : dist;
+            const int id = (int)(row - slab0);  // slab-local, fits 31 bits
+            if (top.beats_tail(dist, id)) top.insert(dist, id);
+          }
+          acc[r] = 0.f;
+        }
+      }
+      if (more) commit(buf ^ 1, nch, nbuf ^ (last ? 1 : 0));
+      sync();
+      buf ^= 1;
+      if (last) nbuf ^= 1;
     }
+    row0 += tile_step;
   }
 
-  // ---- merge the 8 lists (4 waves x 2 halves) of each query inside the workgroup ----
-  __syncthreads();  // every wave is done with its staging buffers before they are reused
+  // ---- merge the lists of each query inside the workgroup ----
+  __syncthreads();  // every wave is done with the staging buffers before they are reused
+  float (*s_mv)[LISTS][K] = reinterpret_cast<float (*)[LISTS][K]>(smem);
+  int (*s_mi)[LISTS][K] = reinterpret_cast<int (*)[LISTS][K]>(smem + (size_t)NQ_WG * LISTS * K * 4);
+  {
+    const int ql = WIDE ? wave * kQT + col : col;
+    const int li = WIDE ? half : wave * 2 + half;
 #pragma unroll
-  for (int p = 0; p < K; ++p) {
-    s_mv[col][wave * 2 + half][p] = top.v[p];
-    s_mi[col][wave * 2 + half][p] = top.id[p];
+    for (int p = 0; p < K; ++p) {
+      s_mv[ql][li][p] = top.v[p];
+      s_mi[ql][li][p] = top.id[p];
+    }
   }
   __syncthreads();
-  if (tid < kQT) {
-    int head[kWaves * 2];
+  if (tid < NQ_WG) {
+    int head[LISTS];
 #pragma unroll
-    for (int l = 0; l < kWaves * 2; ++l) head[l] = 0;
-    const size_t out = (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kQT + tid) * K;
+    for (int l = 0; l < LISTS; ++l) head[l] = 0;
+    const int qtile = WIDE ? blockIdx.y * kWaves + tid / kQT : blockIdx.y;
+    const size_t out = (((size_t)qtile * gridDim.x + blockIdx.x) * kQT + (tid % kQT)) * K;
     for (int p = 0; p < K; ++p) {
       float bv = FLT_MAX;
       int bi = 0x7FFFFFFF, bl = 0;
 #pragma unroll
-      for (int l = 0; l < kWaves * 2; ++l) {
+      for (int l = 0; l < LISTS; ++l) {
         if (head[l] < K) {
           const float v = s_mv[tid][l][head[l]];
           const int i = s_mi[tid][l][head[l]];
@@ -202,11 +261,10 @@ __global__ __launch_bounds__(256, 1) void k_flat_l2(KnnArgs a) {
         }
       }
 #pragma unroll
-      for (int l = 0; l < kWaves * 2; ++l)
+      for (int l = 0; l < LISTS; ++l)
         if (l == bl) head[l]++;
       a.pd[out + p] = bv;
-      // global id, or -1 when fewer than K rows exist
-      a.pi[out + p] = bi == 0x7FFFFFFF ? -1 : bi;
+      a.pi[out + p] = bi == 0x7FFFFFFF ? -1 : bi;  // -1 when fewer than K rows exist
     }
   }
 }
@@ -356,14 +414,14 @@ int norms_for(const float* x, long long n, int d, float* out, hipStream_t stream
   return EIOKU_OK;
 }
 
-template <int K>
+template <int K, bool WIDE>
 int launch_search_k(int d, const KnnArgs& a, dim3 grid, hipStream_t stream) {
   switch (d) {
-    case 64: hipLaunchKernelGGL((k_flat_l2<K, 64>), grid, dim3(256), 0, stream, a); break;
-    case 128: hipLaunchKernelGGL((k_flat_l2<K, 128>), grid, dim3(256), 0, stream, a); break;
-    case 256: hipLaunchKernelGGL((k_flat_l2<K, 256>), grid, dim3(256), 0, stream, a); break;
-    case 384: hipLaunchKernelGGL((k_flat_l2<K, 384>), grid, dim3(256), 0, stream, a); break;
-    case 512: hipLaunchKernelGGL((k_flat_l2<K, 512>), grid, dim3(256), 0, stream, a); break;
+    case 64: hipLaunchKernelGGL((k_flat_l2<K, 64, WIDE>), grid, dim3(256), 0, stream, a); break;
+    case 128: hipLaunchKernelGGL((k_flat_l2<K, 128, WIDE>), grid, dim3(256), 0, stream, a); break;
+    case 256: hipLaunchKernelGGL((k_flat_l2<K, 256, WIDE>), grid, dim3(256), 0, stream, a); break;
+    case 384: hipLaunchKernelGGL((k_flat_l2<K, 384, WIDE>), grid, dim3(256), 0, stream, a); break;
+    case 512: hipLaunchKernelGGL((k_flat_l2<K, 512, WIDE>), grid, dim3(256), 0, stream, a); break;
     default:
       set_error("dimension %d not supported (64, 128, 256, 384, 512)", d);
       return EIOKU_EINVAL;
@@ -474,8 +532,13 @@ int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D,
   const int d = ix->d;
   const int K = k <= 16 ? 16 : 32;
   const int qtiles = (nq + kQT - 1) / kQT;
-  // slabs: ~4 workgroups per CU over the whole grid, slab a multiple of 128 rows
-  long long want = (long long)num_cus() * 4 / qtiles;
+  // wide: 4 query tiles share every staged row tile (one HBM pass per 128 queries)
+  const bool wide = qtiles > 1;
+  const int ygroups = wide ? (qtiles + kWaves - 1) / kWaves : qtiles;
+  // One workgroup is resident per CU (the query tile fills the register file), and a slab that is too
+  // short never leaves the phase where most rows still enter some lane's top-K (the insertion path runs
+  // whenever ANY lane of the wave inserts): ~2 workgroups per CU over the whole grid.
+  long long want = (long long)num_cus() * 2 / ygroups;
   if (want < 1) want = 1;
   long long rpb = (ix->n + want - 1) / want;
   rpb = ((rpb + kRT * kWaves - 1) / (kRT * kWaves)) * (kRT * kWaves);
@@ -496,7 +559,7 @@ int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D,
   if (rc) return rc;
   rc = norms_for(dq, nq, d, ix->qnorm, stream);
   if (rc) return rc;
-  const size_t pn = (size_t)qtiles * slabs * kQT * K;
+  const size_t pn = (size_t)ygroups * (wide ? kWaves : 1) * slabs * kQT * K;
   rc = grow(&ix->pd, &ix->pdcap, pn * sizeof(float));
   if (rc) return rc;
   rc = grow(&ix->pi, &ix->picap, pn * sizeof(int));
@@ -523,9 +586,10 @@ int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D,
   a.pd = ix->pd;
   a.pi = ix->pi;
   a.id_base = 0;
-  dim3 grid((unsigned)slabs, (unsigned)qtiles);
+  dim3 grid((unsigned)slabs, (unsigned)ygroups);
   prof_start(EIOKU_PROF_KNN, stream);
-  rc = K == 16 ? launch_search_k<16>(d, a, grid, stream) : launch_search_k<32>(d, a, grid, stream);
+  if (wide) rc = K == 16 ? launch_search_k<16, true>(d, a, grid, stream) : launch_search_k<32, true>(d, a, grid, stream);
+  else rc = K == 16 ? launch_search_k<16, false>(d, a, grid, stream) : launch_search_k<32, false>(d, a, grid, stream);
   prof_stop(EIOKU_PROF_KNN, stream);
   if (rc) return rc;
   if (K == 16)
