@@ -112,39 +112,57 @@ __global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
   const long long gstride = (long long)gridDim.x * 4;
   long long g = (long long)blockIdx.x * 4 + wave;
 
-  auto load_b = [&](long long grp, int kc, uint4 (&b)[2]) {
+  // B fragments are fetched KB k-steps (KB x 2 x 16 B per lane) at a time, one block ahead of the MFMAs:
+  // with few waves per CU (low-resolution layers) a one-step lookahead leaves every step waiting on L2/HBM.
+  constexpr int KB = 4;
+  const int nkb = (a.nchunks + KB - 1) / KB;
+  auto load_blk = [&](long long grp, int kb, uint4 (&b)[KB][2]) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const long long p = grp * 32 + m * 16 + r;
-      const int c = kc * 32 + u * 8;
-      b[m] = make_uint4(0, 0, 0, 0);
-      if (p < npix && c < a.Cin) b[m] = *reinterpret_cast<const uint4*>(a.in + (size_t)p * a.in_cs + c);
+    for (int j = 0; j < KB; ++j) {
+      const int c = (kb * KB + j) * 32 + u * 8;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const long long p = grp * 32 + m * 16 + r;
+        b[j][m] = make_uint4(0, 0, 0, 0);
+        if (p < npix && c < a.Cin) b[j][m] = *reinterpret_cast<const uint4*>(a.in + (size_t)p * a.in_cs + c);
+      }
     }
   };
 
   float4 biasr[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) biasr[f] = *reinterpret_cast<const float4*>(a.bias + co_tile * ROWS + f * 16 + u * 4);
-  uint4 bn[2];
-  if (g < groups) load_b(g, 0, bn);
+  uint4 bn[KB][2];
+  if (g < groups) load_blk(g, 0, bn);
   for (; g < groups; g += gstride) {
     float4v acc[2][NF];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int f = 0; f < NF; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < a.nchunks; ++kc) {
-      uint4 b[2] = {bn[0], bn[1]};
-      if (kc + 1 < a.nchunks) load_b(g, kc + 1, bn);
-      else if (g + gstride < groups) load_b(g + gstride, 0, bn);  // next group's first step in flight
+    for (int kb = 0; kb < nkb; ++kb) {
+      uint4 b[KB][2];
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const int row = f * 16 + r;
-        uint4 w = wt[(kc * ROWS + row) * 4 + (u ^ ((row >> 1) & 3))];
-        half8 afrag = *reinterpret_cast<half8*>(&w);
+      for (int j = 0; j < KB; ++j) {
+        b[j][0] = bn[j][0];
+        b[j][1] = bn[j][1];
+      }
+      if (kb + 1 < nkb) load_blk(g, kb + 1, bn);
+      else if (g + gstride < groups) load_blk(g + gstride, 0, bn);  // next group's first block in flight
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-          acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, *reinterpret_cast<half8*>(&b[m]), acc[m][f], 0, 0, 0);
+      for (int j = 0; j < KB; ++j) {
+        const int kc = kb * KB + j;
+        if (kc < a.nchunks) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const int row = f * 16 + r;
+            uint4 w = wt[(kc * ROWS + row) * 4 + (u ^ ((row >> 1) & 3))];
+            half8 afrag = *reinterpret_cast<half8*>(&w);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+              acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, *reinterpret_cast<half8*>(&b[j][m]), acc[m][f], 0, 0, 0);
+          }
+        }
       }
     }
 #pragma unroll
@@ -277,13 +295,6 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co_tile = blockIdx.y;
-  {
-    const uint4* wsrc = a.wgt + (size_t)co_tile * NCH * WT_U;
-    for (int idx = tid; idx < NCH * WT_U; idx += 256) {
-      const int row = (idx % WT_U) >> 2, unit = idx & 3;
-      wt[(idx & ~3) + (unit ^ ((row >> 1) & 3))] = wsrc[idx];
-    }
-  }
   // per-thread staging slots: slot j -> (chunk, pixel, unit) is tile independent
   int s_off[R];      // LDS unit index inside one patch buffer, or -1
   int s_py[R], s_px[R], s_c[R];
@@ -327,7 +338,16 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
   const bool res_vec = a.res != nullptr && a.Cout >= 4;  // vector residual path (slices are 4-channel aligned)
 
   int tile = blockIdx.x;
-  if (tile < total_tiles) issue(tile);
+  if (tile < total_tiles) issue(tile);  // first patch in flight while the weight block is copied
+  {
+    const uint4* wsrc = a.wgt + (size_t)co_tile * NCH * WT_U;
+    constexpr int NW = NCH * WT_U;
+#pragma unroll 8
+    for (int idx = tid; idx < NW; idx += 256) {
+      const int row = (idx % WT_U) >> 2, unit = idx & 3;
+      wt[(idx & ~3) + (unit ^ ((row >> 1) & 3))] = wsrc[idx];
+    }
+  }
   int buf = 0;
   for (; tile < total_tiles; tile += gridDim.x) {
     uint4* pb = patch + (DB ? buf : 0) * (NCH * PATCH_U);
