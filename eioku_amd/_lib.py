@@ -84,6 +84,18 @@ SIGNATURES = {
     "eioku_bert_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                    C.c_void_p]),
     "eioku_bert_last_flops": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "eioku_topk_merge_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "eioku_kmeans_update": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "eioku_pq_assign": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eioku_ivf_histogram": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
+    "eioku_ivf_scatter": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "eioku_ivfpq_scan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
 }
 
 _lib = None

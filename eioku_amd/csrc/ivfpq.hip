@@ -1,0 +1,366 @@
+// K10: IVF-PQ building blocks (FAISS IndexIVFPQ semantics, L2, by_residual, nbits = 8).
+//
+// The reference holds intent only for vector search (.kiro/specs/semantic-video-search/design.md:
+// 35-40); BASELINE.json cfg5 names IndexIVF-PQ (100M x 384, nlist 4096).  Host orchestration (training
+// loops, list bookkeeping) is Python (eioku_amd/ivfpq.py); the data-parallel steps are here:
+//
+//   k_kmeans_accumulate  per-cluster sums in 64-bit FIXED POINT (2^-32): integer atomics are
+//                        associative, so centroids are bit-reproducible run to run (float atomics are not)
+//   k_kmeans_finalize    sum / count -> centroid (empty cluster keeps its previous centroid)
+//   k_pq_assign          nearest of 256 sub-centroids per (vector, sub-quantiser) on x - coarse[list]
+//                        (training assignment AND encoding); sub-codebook in LDS
+//   k_ivf_histogram / k_ivf_scatter   counting sort of vectors into inverted lists
+//   k_ivfpq_scan         per (query, probe): residual LUT (m x 256) in LDS, ADC sum over the list's
+//                        codes (HBM-bound: m bytes per code), per-thread top-k, block merge
+//
+// The coarse assignment / probe selection reuses K9 (k_flat_l2 with k = 1 / nprobe).
+#include "common.h"
+
+#include <cfloat>
+
+using namespace eioku;
+
+namespace {
+
+constexpr double kFix = 4294967296.0;  // 2^32
+
+__global__ __launch_bounds__(256) void k_kmeans_accumulate(const float* __restrict__ x, long long n, int d,
+                                                           const long long* __restrict__ assign,
+                                                           long long* __restrict__ sums, int* __restrict__ counts) {
+  // one wave per row: lanes stride the dims
+  const int lane = threadIdx.x & 63;
+  long long row = (blockIdx.x * 256ll + threadIdx.x) >> 6;
+  const long long nw = ((long long)gridDim.x * 256) >> 6;
+  for (; row < n; row += nw) {
+    const long long c = assign[row];
+    if (c < 0) continue;
+    for (int j = lane; j < d; j += 64) {
+      const long long q = __double2ll_rn((double)x[(size_t)row * d + j] * kFix);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&sums[(size_t)c * d + j]), (unsigned long long)q);
+    }
+    if (lane == 0) atomicAdd(&counts[c], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_kmeans_finalize(const long long* __restrict__ sums, const int* __restrict__ counts,
+                                                         int k, int d, float* __restrict__ centroids) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= (long long)k * d) return;
+  const int c = (int)(i / d);
+  if (counts[c] > 0) centroids[i] = (float)(((double)sums[i] / kFix) / (double)counts[c]);
+}
+
+// x: [n][d] ; coarse (optional): [nlist][d] with list[n] -> residual = x - coarse[list]
+// pq: [m][256][dsub] ; codes: [n][m] uint8.  One thread per (vector, sub-quantiser).
+template <int DSUB>
+__global__ __launch_bounds__(256) void k_pq_assign(const float* __restrict__ x, long long n, int d, int m,
+                                                   const float* __restrict__ coarse, const long long* __restrict__ list,
+                                                   const float* __restrict__ pq, uint8_t* __restrict__ codes,
+                                                   float* __restrict__ resid_out) {
+  __shared__ float cb[256 * DSUB];
+  const int j = blockIdx.y;  // sub-quantiser
+  for (int i = threadIdx.x; i < 256 * DSUB; i += 256) cb[i] = pq[(size_t)j * 256 * DSUB + i];
+  __syncthreads();
+  long long row = blockIdx.x * 256ll + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; row < n; row += stride) {
+    float v[DSUB];
+#pragma unroll
+    for (int t = 0; t < DSUB; ++t) v[t] = x[(size_t)row * d + j * DSUB + t];
+    if (coarse) {
+      const long long l = list[row];
+#pragma unroll
+      for (int t = 0; t < DSUB; ++t) v[t] = v[t] - coarse[(size_t)l * d + j * DSUB + t];
+    }
+    if (resid_out) {
+#pragma unroll
+      for (int t = 0; t < DSUB; ++t) resid_out[(size_t)row * d + j * DSUB + t] = v[t];
+    }
+    float best = FLT_MAX;
+    int bi = 0;
+    for (int c = 0; c < 256; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < DSUB; ++t) {
+        const float df = v[t] - cb[c * DSUB + t];
+        s += df * df;
+      }
+      if (s < best) {  // first minimum wins
+        best = s;
+        bi = c;
+      }
+    }
+    if (codes) codes[(size_t)row * m + j] = (uint8_t)bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ivf_histogram(const long long* __restrict__ list, long long n, int* __restrict__ counts) {
+  long long i = blockIdx.x * 256ll + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < n; i += stride) atomicAdd(&counts[list[i]], 1);
+}
+
+// offsets: exclusive prefix of counts (host-computed: nlist is small); cursor starts as a copy of offsets
+__global__ __launch_bounds__(256) void k_ivf_scatter(const long long* __restrict__ list, long long n, int m,
+                                                     const uint8_t* __restrict__ codes, long long id_base,
+                                                     int* __restrict__ cursor, uint8_t* __restrict__ list_codes,
+                                                     long long* __restrict__ list_ids) {
+  long long i = blockIdx.x * 256ll + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < n; i += stride) {
+    const int pos = atomicAdd(&cursor[list[i]], 1);
+    for (int j = 0; j < m; ++j) list_codes[(size_t)pos * m + j] = codes[(size_t)i * m + j];
+    list_ids[pos] = id_base + i;
+  }
+}
+
+// ---- scan -------------------------------------------------------------------------------------------
+template <int K>
+struct SmallTop {
+  float v[K];
+  long long id[K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+      v[p] = FLT_MAX;
+      id[p] = -1;
+    }
+  }
+  __device__ __forceinline__ bool better(float x, long long i, float y, long long j) const {
+    return x < y || (x == y && (j < 0 || i < j));
+  }
+  __device__ __forceinline__ void insert(float x, long long i) {
+    if (!better(x, i, v[K - 1], id[K - 1])) return;
+#pragma unroll
+    for (int p = K - 1; p > 0; --p) {
+      const bool shift = better(x, i, v[p - 1], id[p - 1]);
+      const bool here = !shift && better(x, i, v[p], id[p]);
+      const float nv = shift ? v[p - 1] : (here ? x : v[p]);
+      const long long ni = shift ? id[p - 1] : (here ? i : id[p]);
+      v[p] = nv;
+      id[p] = ni;
+    }
+    if (better(x, i, v[0], id[0])) {
+      v[0] = x;
+      id[0] = i;
+    }
+  }
+};
+
+// grid (nq, nprobe); block 256.  probes: [nq][nprobe] list ids (-1 = none).
+// out: pd/pi [nprobe][nq][K]  (the [list][nq][k] layout k_topk_merge takes)
+template <int K, int DSUB>
+__global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q, int nq, int d, int m,
+                                                    const long long* __restrict__ probes, int nprobe,
+                                                    const float* __restrict__ coarse, const float* __restrict__ pq,
+                                                    const int* __restrict__ offsets, const int* __restrict__ sizes,
+                                                    const uint8_t* __restrict__ list_codes,
+                                                    const long long* __restrict__ list_ids, float* __restrict__ pd,
+                                                    long long* __restrict__ pi) {
+  extern __shared__ __attribute__((aligned(16))) float lut[];  // [m][256], then merge area
+  const int qi = blockIdx.x, pr = blockIdx.y, tid = threadIdx.x;
+  const long long l = probes[(size_t)qi * nprobe + pr];
+  SmallTop<K> top;
+  top.init();
+  if (l >= 0) {
+    // LUT[j][c] = || (q - coarse[l])_j - pq[j][c] ||^2
+    for (int e = tid; e < m * 256; e += 256) {
+      const int j = e >> 8, c = e & 255;
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < DSUB; ++t) {
+        const float r = q[(size_t)qi * d + j * DSUB + t] - coarse[(size_t)l * d + j * DSUB + t];
+        const float df = r - pq[((size_t)j * 256 + c) * DSUB + t];
+        s += df * df;
+      }
+      lut[e] = s;
+    }
+    __syncthreads();
+    const int off = offsets[l], sz = sizes[l];
+    for (int i = tid; i < sz; i += 256) {
+      const uint8_t* code = list_codes + (size_t)(off + i) * m;
+      float s = 0.f;
+      for (int j = 0; j < m; ++j) s += lut[j * 256 + code[j]];
+      top.insert(s, list_ids[off + i]);
+    }
+  }
+  __syncthreads();
+  // block merge: every thread publishes its list, thread 0..K-1 rounds of block argmin are overkill for
+  // K <= 32: serial K-way pick by one wave over 256 heads
+  float* mv = lut;                                                   // [256][K]
+  long long* mi = reinterpret_cast<long long*>(lut + 256 * K);       // [256][K]
+#pragma unroll
+  for (int p = 0; p < K; ++p) {
+    mv[tid * K + p] = top.v[p];
+    mi[tid * K + p] = top.id[p];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int head[4] = {0, 0, 0, 0};  // this lane owns lists tid, tid+64, tid+128, tid+192
+    for (int r = 0; r < K; ++r) {
+      float bv = FLT_MAX;
+      long long bi = -1;
+      int bs = 0;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if (head[s4] < K) {
+          const float v = mv[(tid + 64 * s4) * K + head[s4]];
+          const long long i = mi[(tid + 64 * s4) * K + head[s4]];
+          if (i >= 0 && (v < bv || (v == bv && (bi < 0 || i < bi)))) {
+            bv = v;
+            bi = i;
+            bs = s4;
+          }
+        }
+      }
+      // wave argmin
+      float wv = bv;
+      long long wi = bi < 0 ? 0x7FFFFFFFFFFFFFFFll : bi;
+      int wl = tid;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(wv, o, 64);
+        const long long oi = __shfl_xor(wi, o, 64);
+        const int ol = __shfl_xor(wl, o, 64);
+        if (ov < wv || (ov == wv && oi < wi) || (ov == wv && oi == wi && ol < wl)) {
+          wv = ov;
+          wi = oi;
+          wl = ol;
+        }
+      }
+      const bool found = wi != 0x7FFFFFFFFFFFFFFFll;
+      if (tid == 0) {
+        pd[((size_t)pr * nq + qi) * K + r] = found ? wv : FLT_MAX;
+        pi[((size_t)pr * nq + qi) * K + r] = found ? wi : -1;
+      }
+      if (found && tid == wl) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          if (s4 == bs) head[s4]++;
+      }
+    }
+  }
+}
+
+inline unsigned grid_cap(long long work, int per_block) {
+  long long g = (work + per_block - 1) / per_block;
+  const long long cap = (long long)num_cus() * 16;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+// centroids[k][d] <- mean of the rows assigned to each cluster (assign[i] in [0,k) or -1); clusters
+// without members keep their current centroid.  counts_out[k] (optional, device) receives the sizes.
+int eioku_kmeans_update(const float* x_dev, long long n, int d, const long long* assign_dev, int k,
+                        float* centroids_dev, int* counts_out_dev, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(x_dev && assign_dev && centroids_dev && n >= 0 && d > 0 && k > 0, "bad argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  long long* sums = (long long*)scratch(kSlotWork0, (size_t)k * d * 8);
+  int* counts = (int*)scratch(kSlotWork1, (size_t)k * 4);
+  if (!sums || !counts) return EIOKU_ENOMEM;
+  EIOKU_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)k * d * 8, stream));
+  EIOKU_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)k * 4, stream));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_kmeans_accumulate, dim3(grid_cap(n * 64, 256)), dim3(256), 0, stream, x_dev, n, d, assign_dev,
+                       sums, counts);
+    EIOKU_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_kmeans_finalize, dim3((unsigned)(((long long)k * d + 255) / 256)), dim3(256), 0, stream, sums,
+                     counts, k, d, centroids_dev);
+  EIOKU_LAUNCH_CHECK();
+  if (counts_out_dev)
+    EIOKU_HIP_CHECK(hipMemcpyAsync(counts_out_dev, counts, (size_t)k * 4, hipMemcpyDeviceToDevice, stream));
+  return EIOKU_OK;
+}
+
+// Nearest PQ sub-centroid per (vector, sub-quantiser) of x (or of x - coarse[list] when coarse != NULL).
+// codes_out [n][m] uint8 and/or resid_out [n][d] may be NULL.  d = m * dsub, dsub in {4, 8, 16}.
+int eioku_pq_assign(const float* x_dev, long long n, int d, int m, const float* coarse_dev, const long long* list_dev,
+                    const float* pq_dev, uint8_t* codes_out_dev, float* resid_out_dev, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(x_dev && pq_dev && n >= 0 && d > 0 && m > 0 && d % m == 0, "bad argument");
+  EIOKU_REQUIRE(!coarse_dev || list_dev, "coarse centroids need the list assignment");
+  const int dsub = d / m;
+  EIOKU_REQUIRE(dsub == 4 || dsub == 8 || dsub == 16, "sub-vector size %d not supported (4, 8, 16)", dsub);
+  if (n == 0) return EIOKU_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  dim3 grid(grid_cap(n, 256) / 4 + 1, (unsigned)m);
+  if (dsub == 4) hipLaunchKernelGGL(k_pq_assign<4>, grid, dim3(256), 0, stream, x_dev, n, d, m, coarse_dev, list_dev, pq_dev, codes_out_dev, resid_out_dev);
+  else if (dsub == 8) hipLaunchKernelGGL(k_pq_assign<8>, grid, dim3(256), 0, stream, x_dev, n, d, m, coarse_dev, list_dev, pq_dev, codes_out_dev, resid_out_dev);
+  else hipLaunchKernelGGL(k_pq_assign<16>, grid, dim3(256), 0, stream, x_dev, n, d, m, coarse_dev, list_dev, pq_dev, codes_out_dev, resid_out_dev);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+int eioku_ivf_histogram(const long long* list_dev, long long n, int nlist, int* counts_dev, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(list_dev && counts_dev && nlist > 0, "bad argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  EIOKU_HIP_CHECK(hipMemsetAsync(counts_dev, 0, (size_t)nlist * 4, stream));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_ivf_histogram, dim3(grid_cap(n, 256)), dim3(256), 0, stream, list_dev, n, counts_dev);
+    EIOKU_LAUNCH_CHECK();
+  }
+  return EIOKU_OK;
+}
+
+// cursor_dev: per-list write positions (initialised by the caller to the lists' current ends); on return
+// they have advanced by the number of vectors scattered into each list.
+int eioku_ivf_scatter(const long long* list_dev, long long n, int m, const uint8_t* codes_dev, long long id_base,
+                      int* cursor_dev, uint8_t* list_codes_dev, long long* list_ids_dev, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(list_dev && codes_dev && cursor_dev && list_codes_dev && list_ids_dev && m > 0, "bad argument");
+  if (n == 0) return EIOKU_OK;
+  hipLaunchKernelGGL(k_ivf_scatter, dim3(grid_cap(n, 256)), dim3(256), 0, (hipStream_t)stream_, list_dev, n, m, codes_dev,
+                     id_base, cursor_dev, list_codes_dev, list_ids_dev);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+// ADC scan of the probed lists.  Partial results pd/pi are [nprobe][nq][K] with K = 16 (k <= 16) or 32;
+// merge them with eioku_topk_merge(pd, pi, nprobe, nq, K -> k ...).
+int eioku_ivfpq_scan(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe,
+                     const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
+                     const uint8_t* list_codes_dev, const long long* list_ids_dev, int k, float* pd_dev,
+                     long long* pi_dev, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(q_dev && probes_dev && coarse_dev && pq_dev && offsets_dev && sizes_dev && pd_dev && pi_dev, "NULL buffer");
+  EIOKU_REQUIRE(nq >= 0 && nprobe > 0 && k >= 1 && k <= 32 && d % m == 0, "bad argument");
+  const int dsub = d / m;
+  EIOKU_REQUIRE(dsub == 4 || dsub == 8 || dsub == 16, "sub-vector size %d not supported (4, 8, 16)", dsub);
+  if (nq == 0) return EIOKU_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int K = k <= 16 ? 16 : 32;
+  size_t lds = (size_t)m * 256 * 4;
+  const size_t merge = (size_t)256 * K * 12;
+  if (merge > lds) lds = merge;
+  EIOKU_REQUIRE(lds <= 150 * 1024, "m=%d needs %zu bytes of LDS", m, lds);
+  dim3 grid((unsigned)nq, (unsigned)nprobe);
+#define EIOKU_SCAN(K_, D_)                                                                                     \
+  {                                                                                                            \
+    static bool attr = false;                                                                                  \
+    if (!attr) {                                                                                               \
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ivfpq_scan<K_, D_>),                 \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));            \
+      attr = true;                                                                                             \
+    }                                                                                                          \
+    hipLaunchKernelGGL((k_ivfpq_scan<K_, D_>), grid, dim3(256), lds, stream, q_dev, nq, d, m, probes_dev, nprobe, \
+                       coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev, list_ids_dev, pd_dev, pi_dev); \
+  }
+  if (K == 16) {
+    if (dsub == 4) EIOKU_SCAN(16, 4) else if (dsub == 8) EIOKU_SCAN(16, 8) else EIOKU_SCAN(16, 16)
+  } else {
+    if (dsub == 4) EIOKU_SCAN(32, 4) else if (dsub == 8) EIOKU_SCAN(32, 8) else EIOKU_SCAN(32, 16)
+  }
+#undef EIOKU_SCAN
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+}  // extern "C"

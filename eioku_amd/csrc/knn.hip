@@ -530,7 +530,7 @@ int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D,
   EIOKU_REQUIRE(q && D && I, "NULL buffer");
   hipStream_t stream = (hipStream_t)stream_;
   const int d = ix->d;
-  const int K = k <= 16 ? 16 : 32;
+  const int K = k == 1 ? 1 : (k <= 16 ? 16 : 32);  // k == 1: coarse assignment (k-means / IVF), a single compare per row
   const int qtiles = (nq + kQT - 1) / kQT;
   // wide: 4 query tiles share every staged row tile (one HBM pass per 128 queries)
   const bool wide = qtiles > 1;
@@ -588,11 +588,15 @@ int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D,
   a.id_base = 0;
   dim3 grid((unsigned)slabs, (unsigned)ygroups);
   prof_start(EIOKU_PROF_KNN, stream);
-  if (wide) rc = K == 16 ? launch_search_k<16, true>(d, a, grid, stream) : launch_search_k<32, true>(d, a, grid, stream);
+  if (K == 1) rc = wide ? launch_search_k<1, true>(d, a, grid, stream) : launch_search_k<1, false>(d, a, grid, stream);
+  else if (wide) rc = K == 16 ? launch_search_k<16, true>(d, a, grid, stream) : launch_search_k<32, true>(d, a, grid, stream);
   else rc = K == 16 ? launch_search_k<16, false>(d, a, grid, stream) : launch_search_k<32, false>(d, a, grid, stream);
   prof_stop(EIOKU_PROF_KNN, stream);
   if (rc) return rc;
-  if (K == 16)
+  if (K == 1)
+    hipLaunchKernelGGL((k_topk_merge<1>), dim3(nq), dim3(64), 0, stream, ix->pd, ix->pi, (const long long*)nullptr,
+                       (int)slabs, nq, K, 1, (const long long*)nullptr, rpb, k, dD, dI);
+  else if (K == 16)
     hipLaunchKernelGGL((k_topk_merge<16>), dim3(nq), dim3(64), 0, stream, ix->pd, ix->pi, (const long long*)nullptr,
                        (int)slabs, nq, K, 1, (const long long*)nullptr, rpb, k, dD, dI);
   else
@@ -610,21 +614,26 @@ int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D,
 // Merge `nlists` per-shard results (each [nq][k] ascending, ids already global, -1 = empty) into the
 // global top-k.  Device pointers; d_lists / i_lists are [nlists][nq][k] contiguous (the layout an
 // all-gather of per-rank (D, I) produces).
-int eioku_topk_merge(const float* d_lists, const int64_t* i_lists, int nlists, int nq, int k, float* D,
-                     int64_t* I, void* stream_) {
+int eioku_topk_merge_ex(const float* d_lists, const int64_t* i_lists, int nlists, int nq, int k_in, int k, float* D,
+                        int64_t* I, void* stream_) {
   EIOKU_REQUIRE_INIT();
-  EIOKU_REQUIRE(nlists >= 1 && nq >= 0 && k >= 1 && k <= 32, "bad argument");
+  EIOKU_REQUIRE(nlists >= 1 && nq >= 0 && k >= 1 && k <= 32 && k_in >= k, "bad argument");
   if (nq == 0) return EIOKU_OK;
   EIOKU_REQUIRE(d_lists && i_lists && D && I, "NULL buffer");
   hipStream_t stream = (hipStream_t)stream_;
   if (k <= 16)
     hipLaunchKernelGGL((k_topk_merge<16>), dim3(nq), dim3(64), 0, stream, d_lists, (const int*)nullptr,
-                       (const long long*)i_lists, nlists, nq, k, 0, (const long long*)nullptr, 0ll, k, D, (long long*)I);
+                       (const long long*)i_lists, nlists, nq, k_in, 0, (const long long*)nullptr, 0ll, k, D, (long long*)I);
   else
     hipLaunchKernelGGL((k_topk_merge<32>), dim3(nq), dim3(64), 0, stream, d_lists, (const int*)nullptr,
-                       (const long long*)i_lists, nlists, nq, k, 0, (const long long*)nullptr, 0ll, k, D, (long long*)I);
+                       (const long long*)i_lists, nlists, nq, k_in, 0, (const long long*)nullptr, 0ll, k, D, (long long*)I);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
+}
+
+int eioku_topk_merge(const float* d_lists, const int64_t* i_lists, int nlists, int nq, int k, float* D,
+                     int64_t* I, void* stream_) {
+  return eioku_topk_merge_ex(d_lists, i_lists, nlists, nq, k, k, D, I, stream_);
 }
 
 }  // extern "C"

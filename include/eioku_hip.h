@@ -229,6 +229,35 @@ int eioku_bert_embed(eioku_bert_t* m, const int32_t* ids, const uint8_t* mask, i
                      int mem, void* stream);
 int eioku_bert_last_flops(const eioku_bert_t* m, double* flops);
 
+/* as eioku_topk_merge, for lists that carry k_in >= k entries each ([nlists][nq][k_in]) */
+int eioku_topk_merge_ex(const float* d_lists, const int64_t* i_lists, int nlists, int nq, int k_in, int k,
+                        float* D, int64_t* I, void* stream);
+
+/* ---- approximate kNN: IVF-PQ building blocks (FAISS IndexIVFPQ semantics: L2, by_residual, 8 bit) ----
+ * BASELINE.json cfg5.  Host orchestration (k-means / PQ training loops, list bookkeeping) lives in
+ * eioku_amd/ivfpq.py; coarse assignment and probe selection reuse eioku_index_search (k = 1 / nprobe).
+ * All pointers are DEVICE pointers; calls are asynchronous on `stream`.
+ *   eioku_kmeans_update : centroids[k][d] <- mean of assigned rows (64-bit fixed-point atomics: bit
+ *                         reproducible); empty clusters keep their centroid; counts_out optional.
+ *   eioku_pq_assign     : nearest of 256 sub-centroids per (vector, sub-quantiser) of x - coarse[list]
+ *                         (coarse may be NULL); codes_out [n][m] u8 and/or resid_out [n][d], d/m in {4,8,16}.
+ *   eioku_ivf_histogram / eioku_ivf_scatter : counting sort of encoded vectors into inverted lists.
+ *   eioku_ivfpq_scan    : ADC over the probed lists; partial results [nprobe][nq][K], K = 16 (k <= 16)
+ *                         or 32, to be merged with eioku_topk_merge_ex.
+ */
+int eioku_kmeans_update(const float* x_dev, long long n, int d, const long long* assign_dev, int k,
+                        float* centroids_dev, int* counts_out_dev, void* stream);
+int eioku_pq_assign(const float* x_dev, long long n, int d, int m, const float* coarse_dev,
+                    const long long* list_dev, const float* pq_dev, uint8_t* codes_out_dev,
+                    float* resid_out_dev, void* stream);
+int eioku_ivf_histogram(const long long* list_dev, long long n, int nlist, int* counts_dev, void* stream);
+int eioku_ivf_scatter(const long long* list_dev, long long n, int m, const uint8_t* codes_dev, long long id_base,
+                      int* cursor_dev, uint8_t* list_codes_dev, long long* list_ids_dev, void* stream);
+int eioku_ivfpq_scan(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe,
+                     const float* coarse_dev, const float* pq_dev, const int* offsets_dev,
+                     const int* sizes_dev, const uint8_t* list_codes_dev, const long long* list_ids_dev,
+                     int k, float* pd_dev, long long* pi_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
