@@ -154,15 +154,19 @@ def knn_part(args, device, rank, world):
     per = dt / args.knn_iters
     passes = (args.knn_nq + 31) // 32
     alg_bytes = float(hi - lo) * d * 4 * passes  # N*d*4 bytes per 32-query pass, this rank's shard
-    kernel_s = ms * 1e-3 / max(cnt, 1)
+    kernel_s = max(ms * 1e-3 / max(cnt, 1), 1e-9)
+    flops = 2.0 * args.knn_nq * (hi - lo) * d
     out = {"metric": f"kNN QPS@top-10 over {args.knn_n}x{d}", "value": args.knn_nq / per, "unit": "queries/s",
            "nq": args.knn_nq, "k": k, "ms_per_search": per * 1e3, "n_total": args.knn_n, "rows_per_gpu": hi - lo,
            "dtype": "f32", "collective": "none" if world == 1 else "all_gather_into_tensor (RCCL) of nq*k*16 B per rank",
-           "roofline": {"kernel": "k_flat_l2", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                        "achieved": alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0,
-                        "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS if kernel_s > 0 else 0.0,
-                        "avg_kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
-                        "mfma_f32_tflops": 2.0 * args.knn_nq * (hi - lo) * d / kernel_s / 1e12 if kernel_s > 0 else 0.0}}
+           "roofline": ({"kernel": "k_flat_l2 (wide: one DB pass per 128 queries)", "bound": "mfma", "unit": "TFLOP/s",
+                         "peak": MFMA_F32_PEAK_TFLOPS, "achieved": flops / kernel_s / 1e12, "frac": flops / kernel_s / 1e12 / MFMA_F32_PEAK_TFLOPS}
+                        if args.knn_nq > 32 else
+                        {"kernel": "k_flat_l2 (narrow)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                         "achieved": alg_bytes / kernel_s / 1e9, "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS})}
+    out["roofline"].update({"avg_kernel_ms": kernel_s * 1e3, "algorithmic_flops_per_launch": flops,
+                            "algorithmic_bytes_per_32query_pass": float(hi - lo) * d * 4,
+                            "hbm_bytes_streamed_per_launch": float(hi - lo) * d * 4 * ((args.knn_nq + 127) // 128 if args.knn_nq > 32 else 1)})
     ix.close()
     del xb
     torch.cuda.empty_cache()
@@ -256,6 +260,12 @@ def main():
         elapsed = float(t.item())
 
     dom = pipe.dominant()
+    # HBM traffic of the dominant kernel family from PMC counters (tools/pmc_traffic.sh: separate FETCH_SIZE /
+    # WRITE_SIZE passes, gfx950 x2 read correction), measured offline on this exact workload and committed
+    traffic = None
+    tfile = ROOT / "profiles" / f"r01_traffic_conv_{Path(args.model).stem}_{args.batch}x{args.height}x{args.width}.json"
+    if pipe.det is not None and tfile.exists():
+        traffic = json.loads(tfile.read_text())["hbm_bytes_per_forward"]
     avg_ms = dom["ms_total"] / max(dom["launches"], 1)
     achieved = dom["alg_total"] / (dom["ms_total"] * 1e-3) / dom["scale"] if dom["ms_total"] > 0 else 0.0
     frames_total = args.batch * args.steps * world
@@ -279,7 +289,8 @@ def main():
                                f"segments x {args.seq_len} tokens per step; stages run: {', '.join(pipe.stages)}{note}",
                    "batch": args.batch, "frame": [args.height, args.width], "parallelism": f"shard-by-video x{world}"},
         "roofline": {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": achieved, "peak": dom["peak"],
-                     "unit": dom["unit"], "frac": achieved / dom["peak"], "traffic": None,
+                     "unit": dom["unit"], "frac": achieved / dom["peak"], "traffic": traffic,
+                     "traffic_note": "HBM bytes per step (all conv launches), PMC FETCH_SIZE x2 + WRITE_SIZE" if traffic else None,
                      "avg_kernel_ms": avg_ms, "launches": dom["launches"], "kernel_ms_per_step": dom["ms_total"] / args.steps,
                      "algorithmic_per_step": dom["alg_per_step"]},
     }
