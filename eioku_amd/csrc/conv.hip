@@ -60,9 +60,13 @@ __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc
   }
   if (a.out_f32) {
     float* o = a.out_f32 + opix * a.Cout + c0;
+    if (c0 + 3 < a.Cout && (a.Cout & 3) == 0) {
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (c0 + j < a.Cout) o[j] = v[j];
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < a.Cout) o[j] = v[j];
+    }
     return;
   }
   __half h[4];
@@ -297,12 +301,12 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
   const int co_tile = blockIdx.y;
   // per-thread staging slots: slot j -> (chunk, pixel, unit) is tile independent
   int s_off[R];      // LDS unit index inside one patch buffer, or -1
-  int s_py[R], s_px[R], s_c[R];
+  int s_py[R], s_px[R], s_rel[R];  // s_rel: element offset of the slot relative to the tile's (ih0, iw0) pixel
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int idx = tid + 256 * j;
     s_off[j] = -1;
-    s_py[j] = s_px[j] = s_c[j] = 0;
+    s_py[j] = s_px[j] = s_rel[j] = 0;
     if (idx < NLOAD) {
       const int cc = idx / (PH * PW * 4), rem = idx - cc * (PH * PW * 4);
       const int pix = rem >> 2, unit = rem & 3;
@@ -312,7 +316,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
       s_off[j] = cc * PATCH_U + p * 4 + (unit ^ ((p >> 1) & 3));
       s_py[j] = py;
       s_px[j] = px;
-      s_c[j] = cc * 32 + unit * 8;
+      s_rel[j] = (py * a.W + px) * a.in_cs + cc * 32 + unit * 8;
+      if (cc * 32 + unit * 8 >= a.Cin) s_off[j] = -2 - s_off[j];  // zero-filled slot: still written, never loaded
     }
   }
   const int tiles_per_img = a.tiles_w * a.tiles_h;
@@ -321,16 +326,30 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
     const int n = tile / tiles_per_img, t2 = tile - n * tiles_per_img;
     const int th = t2 / a.tiles_w, tw = t2 - th * a.tiles_w;
     const int ih0 = th * kTH * S - PAD, iw0 = tw * kTW * S - PAD;
-    const __half* in_n = a.in + (size_t)n * a.H * a.W * a.in_cs;
+    // (ih0, iw0) may lie outside the image: the base is only dereferenced through in-range slots
+    const __half* base = a.in + ((size_t)n * a.H * a.W + (long long)ih0 * a.W + iw0) * a.in_cs;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const int ih = ih0 + s_py[j], iw = iw0 + s_px[j];
       stage[j] = make_uint4(0, 0, 0, 0);
-      if (s_off[j] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W && s_c[j] < a.Cin)
-        stage[j] = *reinterpret_cast<const uint4*>(in_n + ((size_t)ih * a.W + iw) * a.in_cs + s_c[j]);
+      if (s_off[j] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+        stage[j] = *reinterpret_cast<const uint4*>(base + s_rel[j]);
     }
   };
 
+  // B-fragment unit positions inside a chunk's patch: they depend on (lane, tap, m) only, so the swizzle
+  // arithmetic leaves the tile loop (it was ~2.5 VALU per MFMA on a VALU-issue-bound kernel)
+  int bpos[TAPS][2];
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int py = (wave * 2 + m) * S + tap / KS;
+      const int px = (lane & 15) * S + tap % KS;
+      const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
+      const int p = py * PWS + col;
+      bpos[tap][m] = p * 4 + ((lane >> 4) ^ ((p >> 1) & 3));
+    }
   float4 biasr[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f)
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
     if (!DB) __syncthreads();  // single buffer: every wave is done reading the previous tile
 #pragma unroll
     for (int j = 0; j < R; ++j)
-      if (s_off[j] >= 0) pb[s_off[j]] = stage[j];
+      if (s_off[j] != -1) pb[s_off[j] >= 0 ? s_off[j] : -2 - s_off[j]] = stage[j];
     __syncthreads();  // also orders the weight copy before the first tile
     const int tn = tile / tiles_per_img, tt2 = tile - tn * tiles_per_img;
     const int tth = tt2 / a.tiles_w, ttw = tt2 - tth * a.tiles_w;
@@ -388,15 +407,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
     for (int cc = 0; cc < NCH; ++cc) {
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap) {
-        const int kh = tap / KS, kw = tap % KS;
         half8 bfrag[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const int py = (wave * 2 + m) * S + kh;
-          const int px = (lane & 15) * S + kw;
-          const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
-          const int p = py * PWS + col;
-          uint4 u = pb[cc * PATCH_U + p * 4 + ((lane >> 4) ^ ((p >> 1) & 3))];
+          uint4 u = pb[cc * PATCH_U + bpos[tap][m]];
           bfrag[m] = *reinterpret_cast<half8*>(&u);
         }
 #pragma unroll
@@ -543,7 +557,12 @@ int pick_nf(int cout, int ks, int nchunks, int stride) {
     // two workgroups per CU with a single-buffered patch; otherwise fall through to the generic rule
     for (int nf : {4, 3, 2, 1}) {
       const int waste = ((frags + nf - 1) / nf) * nf - frags;
-      if (waste <= (frags >= 4 ? 1 : 0) && persist_lds(nf, stride, nchunks, false) <= 75 * 1024) return nf;
+      if (waste <= (frags >= 4 ? 1 : 0) && persist_lds(nf, stride, nchunks, false) <= 75 * 1024) {
+        // a 1-fragment tile re-reads the halo patch once per 16 couts and is LDS-read bound (3 reads per 2
+        // MFMAs): with >= 5 fragments take 3 per tile even if only one workgroup then fits per CU
+        if (nf == 1 && frags >= 5 && persist_lds(3, stride, nchunks, false) <= 150 * 1024) return 3;
+        return nf;
+      }
     }
   }
   const int cands[] = {8, 6, 5, 4, 3, 2, 1};

@@ -1,0 +1,27 @@
+"""Per-layer table of the last forward in a rocprofv3 kernel trace: time vs bytes/flops of each conv."""
+import csv, glob, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eioku_amd import weights as W
+variant, batch, H = sys.argv[2] if len(sys.argv) > 2 else 'n', int(sys.argv[3]) if len(sys.argv) > 3 else 64, 640
+tab = W.conv_table(variant, 80)
+def level(name):
+    m = re.match(r'model\.(\d+)', name); i = int(m.group(1))
+    if i == 22: return 3 + int(name.split('.')[3])
+    return {0:0,1:1,2:2,3:2,4:3,5:3,6:4,7:4,8:5,9:5,12:4,15:3,16:3,18:4,19:4,21:5}[i]
+fs = sorted(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)
+rows = [r for r in csv.DictReader(open(fs[-1])) if 'k_conv' in r['Kernel_Name']]
+last = rows[-len(tab):]
+tot_t = tot_b = tot_f = 0
+print(f"{'layer':28s} {'shape':22s} {'kernel':28s} {'grid':>9s} {'us':>7s} {'MB':>7s} {'GB/s':>6s} {'TF/s':>6s}")
+for (name, cout, cin, k, s), r in zip(tab, last):
+    lv = level(name); hin = H >> lv; hout = hin // s
+    cin_eff = 8 if name == 'model.0.conv' else cin
+    px_in, px_out = batch * hin * hin, batch * hout * hout
+    obytes = 4 if re.search(r'cv[23]\.\d\.2$', name) else 2
+    by = px_in * cin_eff * 2 + px_out * cout * obytes
+    fl = 2.0 * px_out * cout * cin * k * k
+    us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    kn = re.search(r'(k_conv\w+<[^>]*>)', r['Kernel_Name']).group(1)
+    tot_t += us; tot_b += by; tot_f += fl
+    print(f"{name:28s} {cin:4d}->{cout:4d} k{k}s{s} @{hout:3d} {kn:28s} {int(r['Grid_Size_X'])//256:5d}x{r['Grid_Size_Y']:>3s} {us:7.1f} {by/1e6:7.1f} {by/us/1e3:6.0f} {fl/us/1e6:6.1f}")
+print(f"TOTAL {tot_t:.1f} us, {tot_b/1e9:.2f} GB -> {tot_b/tot_t/1e3:.0f} GB/s, {tot_f/1e9:.1f} GFLOP -> {tot_f/tot_t/1e6:.1f} TF/s")
