@@ -41,6 +41,18 @@ struct ConvArgs {
   int tiles_w, tiles_h, nchunks, act;
 };
 
+// x / d for 0 <= x < 2^24 (exact int->float) with a precomputed 1.0f/d: one multiply and a +-1 fix-up instead
+// of the ~40-instruction integer division (the flattened kernel does ~20 of them before its first load)
+__device__ __forceinline__ int fast_div(int x, int d, float rd) {
+  int q = (int)((float)x * rd);
+  const int r = x - q * d;
+  if (r >= d) ++q;
+  if (r < 0) --q;
+  return q;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ float silu_f32(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
@@ -276,6 +288,173 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Deep-K 3x3 variant for the low-resolution half of the network (Cin >= 128 at 40x40 / 20x20): the
+// 8x16 spatial tile wastes up to half of every MFMA on a 20-wide map, so here a workgroup owns 64*MT
+// CONSECUTIVE output pixels of the flattened (n, y, x) order, across rows and across frames.  The halo
+// patch is cut from a "virtual tall image": frames stacked with ONE shared zero row between them
+// (row v = n*(H+1) is y = -1 of frame n and y = H of frame n-1), so a tile that crosses a frame border
+// still sees the right zero padding.  Zero positions are written once; per-slot addresses are
+// computed once per workgroup; every chunk is (batched global loads -> registers) one step ahead of
+// the MFMAs that consume the previous chunk.
+// ---------------------------------------------------------------------------------------------
+// One 32-channel chunk of a 3x3 convolution out of LDS: 9 taps x (MT pixel fragments x NF cout fragments).
+// The fragments of tap t+1 are read while the MFMAs of tap t issue (two register sets), and the
+// sched_group_barriers pin that interleaving: left alone the scheduler emits read -> lgkmcnt(0) -> MFMA pairs,
+// which exposes the LDS latency once per tap at the 1-2 waves per SIMD these kernels run with.
+// `wt_lane` = weight tile + this lane's swizzled row unit; fragment (tap, f) sits (tap*NF + f)*64 units further.
+template <int NF, int MT>
+__device__ __forceinline__ void mma_taps(const uint4* patch, const uint4* wt_lane, const int (&bpos)[9][MT],
+                                         float4v (&acc)[MT][NF]) {
+  half8 af[2][NF], bf[2][MT];
+  auto ld = [&](int tap, int s) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      uint4 u = patch[bpos[tap][m]];
+      bf[s][m] = *reinterpret_cast<half8*>(&u);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      uint4 u = wt_lane[(tap * NF + f) * 64];
+      af[s][f] = *reinterpret_cast<half8*>(&u);
+    }
+  };
+  ld(0, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, NF + MT, 0);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int s = tap & 1;
+    if (tap + 1 < 9) ld(tap + 1, s ^ 1);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s][f], bf[s][m], acc[m][f], 0, 0, 0);
+    if (tap + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, NF + MT, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NF * MT, 0);
+  }
+}
+
+template <int NF, int S, int MT, int NS>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_flat(ConvArgs a, int npix, int PR, int PW) {
+  constexpr int TAPS = 9, KS = 3;
+  constexpr int WT_U = TAPS * 16 * NF * 4;
+  constexpr int WREG = (WT_U + 255) / 256;
+  constexpr int TPX = 64 * MT;
+  const int PWH = (PW + 1) / 2;
+  const int PWS = (S == 2) ? 2 * PWH : PW;
+  const int DUMMY = PR * PWS * 4;  // one spare unit: where slots that carry nothing park their store
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* patch = reinterpret_cast<uint4*>(smem);
+  uint4* wt = patch + DUMMY + 4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P0 = blockIdx.x * TPX;
+  const int co_tile = blockIdx.y;
+  const int HW = a.Ho * a.Wo, VH = a.H + 1;
+  const float r_hw = 1.0f / (float)HW, r_wo = 1.0f / (float)a.Wo, r_vh = 1.0f / (float)VH, r_pw = 1.0f / (float)PW;
+  auto vrow = [&](int P) {
+    const int n = fast_div(P, HW, r_hw), rem = P - n * HW;
+    return n * VH + fast_div(rem, a.Wo, r_wo) * S;
+  };
+  const int Plast = (P0 + TPX < npix ? P0 + TPX : npix) - 1;
+  const int v_lo = vrow(P0);
+  const int rows = vrow(Plast) + KS - v_lo;
+
+  // staging slots, branch-free in the chunk loop: a slot that maps to padding (or to nothing) loads element 0
+  // and stores to the spare unit; the padding itself is zeroed once, below
+  int s_g[NS], s_l[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int idx = tid + j * 256;
+    const int pix = idx >> 2, unit = idx & 3;
+    const int pr = fast_div(pix, PW, r_pw), pc = pix - pr * PW;
+    const int v = v_lo + pr;
+    const int n = fast_div(v, VH, r_vh), y = v - n * VH - 1, x = pc - 1;
+    const bool ok = idx < rows * PW * 4 && y >= 0 && n < a.N && (unsigned)x < (unsigned)a.W;
+    const int col = (S == 2) ? ((pc & 1) * PWH + (pc >> 1)) : pc;
+    const int p = pr * PWS + col;
+    s_g[j] = ok ? ((n * a.H + y) * a.W + x) * a.in_cs + unit * 8 : 0;
+    s_l[j] = ok ? p * 4 + (unit ^ ((p >> 1) & 3)) : DUMMY;
+  }
+  const uint4* wsrc = a.wgt + (size_t)co_tile * a.nchunks * WT_U + tid;
+  u32x4 sreg[NS], wreg[WREG];
+  const bool cin_tail = (a.Cin & 31) != 0;
+  auto fetch = [&](int cc) {
+    const __half* src = a.in + cc * 32;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) sreg[j] = *reinterpret_cast<const u32x4*>(src + s_g[j]);
+#pragma unroll
+    for (int j = 0; j < WREG; ++j)
+      if (WT_U % 256 == 0 || tid + j * 256 < WT_U) wreg[j] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)cc * WT_U + j * 256);
+    if (cin_tail && cc * 32 + (tid & 3) * 8 >= a.Cin) {  // channels past Cin (weights there are zero; the data may be anything)
+#pragma unroll
+      for (int j = 0; j < NS; ++j) sreg[j] = u32x4{0, 0, 0, 0};
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) *reinterpret_cast<u32x4*>(patch + s_l[j]) = sreg[j];
+#pragma unroll
+    for (int j = 0; j < WREG; ++j) {
+      const int idx = tid + j * 256;
+      const int row = idx >> 2, unit = idx & 3;
+      if (WT_U % 256 == 0 || idx < WT_U) *reinterpret_cast<u32x4*>(wt + row * 4 + (unit ^ ((row >> 1) & 3))) = wreg[j];
+    }
+  };
+  fetch(0);
+
+  for (int i = tid; i < rows * PWS * 4; i += 256) patch[i] = make_uint4(0, 0, 0, 0);
+
+  // B-fragment positions of this lane's MT pixels for the 9 taps
+  int bpos[TAPS][MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int P = P0 + (wave * MT + m) * 16 + (lane & 15);
+    if (P > Plast) P = Plast;
+    const int n = fast_div(P, HW, r_hw), rem = P - n * HW;
+    const int yo = fast_div(rem, a.Wo, r_wo), xo = rem - yo * a.Wo;
+    const int pr0 = n * VH + yo * S - v_lo;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int pc = xo * S + tap % KS;
+      const int col = (S == 2) ? ((pc & 1) * PWH + (pc >> 1)) : pc;
+      const int p = (pr0 + tap / KS) * PWS + col;
+      bpos[tap][m] = p * 4 + ((lane >> 4) ^ ((p >> 1) & 3));
+    }
+  }
+  const uint4* wt_lane = wt + (lane & 15) * 4 + ((lane >> 4) ^ ((lane >> 1) & 3));
+
+  float4v acc[MT][NF];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  __syncthreads();  // zero fill complete before the first commit
+  for (int cc = 0; cc < a.nchunks; ++cc) {
+    commit();
+    __syncthreads();
+    if (cc + 1 < a.nchunks) fetch(cc + 1);  // in flight behind the 9 taps below
+    __builtin_amdgcn_sched_barrier(0);
+    mma_taps<NF, MT>(patch, wt_lane, bpos, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int P = P0 + (wave * MT + m) * 16 + (lane & 15);
+    if (P > Plast) continue;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int c0 = co_tile * 16 * NF + f * 16 + (lane >> 4) * 4;
+      store_frag(a, acc[m][f], (size_t)P, c0, *reinterpret_cast<const float4*>(a.bias + c0));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Persistent 3x3 variant for the layers that dominate the pixel count (Cin <= 96): the whole weight
 // block of the cout tile (NCH chunks x 9 taps) stays in LDS for the launch, workgroups walk the
 // output tiles grid-stride, and the NEXT tile's halo patch is already in flight (registers) while the
@@ -482,6 +661,71 @@ int launch_persist_dispatch(int nf, int nch, bool db, const ConvArgs& a, int nti
   return EIOKU_OK;
 }
 
+// Flattened-pixel deep-K launch: geometry of the worst-case patch, then the largest tile whose staging
+// fits the per-thread slot budget.  *handled = false leaves the layer to the generic kernel.
+struct FlatGeom {
+  int PR, PW, slots;
+  size_t lds;
+};
+template <int S>
+FlatGeom flat_geom(const ConvArgs& a, int nf, int mt) {
+  const int tpx = 64 * mt;
+  const int r_o = (a.Wo - 2 + tpx) / a.Wo + 1;
+  int cross = (tpx - 1) / (a.Ho * a.Wo) + 1;
+  if (cross > r_o - 1) cross = r_o - 1;
+  const int extra = (a.H + 1) - a.Ho * S;
+  FlatGeom g;
+  g.PR = (r_o - 1) * S + 3 + cross * (extra > 0 ? extra : 0);
+  g.PW = (a.Wo - 1) * S + 3;
+  const int pws = (S == 2) ? 2 * ((g.PW + 1) / 2) : g.PW;
+  g.slots = (g.PR * g.PW * 4 + 255) / 256;
+  g.lds = ((size_t)g.PR * pws * 4 + 4 + 9 * 16 * nf * 4) * 16;
+  return g;
+}
+
+template <int NF, int S, int MT, int NS>
+int launch_flat(const ConvArgs& a, const FlatGeom& g, int ntiles, hipStream_t stream) {
+  static size_t attr = 0;
+  if (g.lds > 64 * 1024 && g.lds > attr) {
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_flat<NF, S, MT, NS>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+    attr = g.lds;
+  }
+  const int npix = a.N * a.Ho * a.Wo;
+  const int tpx = 64 * MT;
+  hipLaunchKernelGGL((k_conv3x3_flat<NF, S, MT, NS>), dim3((unsigned)((npix + tpx - 1) / tpx), (unsigned)ntiles),
+                     dim3(256), g.lds, stream, a, npix, g.PR, g.PW);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+template <int S>
+int launch_flat_dispatch(int nf, const ConvArgs& a, int ntiles, hipStream_t stream, bool* handled) {
+  *handled = false;
+  // 32-bit element offsets; pixel / virtual-row indices below 2^24 (fast_div)
+  if ((long long)a.N * a.H * a.W * a.in_cs >= (1ll << 31) || (long long)a.N * (a.H + 1) * (a.W + 2) >= (1ll << 24)) return EIOKU_OK;
+  static const bool off = getenv("EIOKU_CONV_FLAT") && atoi(getenv("EIOKU_CONV_FLAT")) == 0;
+  if (off) return EIOKU_OK;
+  int mt = 2;
+  FlatGeom g = flat_geom<S>(a, nf, mt);
+  if (g.slots > 8 || g.lds > 80 * 1024) {
+    mt = 1;
+    g = flat_geom<S>(a, nf, mt);
+  }
+  if (g.slots > 8 || g.lds > 150 * 1024) return EIOKU_OK;
+  *handled = true;
+#define EIOKU_F(NF_)                                                                                             \
+  if (nf == NF_) {                                                                                                \
+    if (g.slots <= 4)                                                                                             \
+      return mt == 2 ? launch_flat<NF_, S, 2, 4>(a, g, ntiles, stream) : launch_flat<NF_, S, 1, 4>(a, g, ntiles, stream); \
+    return mt == 2 ? launch_flat<NF_, S, 2, 8>(a, g, ntiles, stream) : launch_flat<NF_, S, 1, 8>(a, g, ntiles, stream);   \
+  }
+  EIOKU_F(2) EIOKU_F(3) EIOKU_F(4) EIOKU_F(5) EIOKU_F(6)
+#undef EIOKU_F
+  *handled = false;
+  return EIOKU_OK;
+}
+
 template <int NF, int KS, int S>
 int launch(const ConvArgs& a, int ntiles, hipStream_t stream) {
   constexpr int PH = (kTH - 1) * S + KS;
@@ -667,6 +911,9 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
       rc = cw.stride == 1 ? launch_persist_dispatch<1>(cw.nf, cw.nchunks, db, a, cw.ntiles, stream, &handled)
                           : launch_persist_dispatch<2>(cw.nf, cw.nchunks, db, a, cw.ntiles, stream, &handled);
   }
+  if (!handled && cw.ks == 3 && cw.nchunks > 3 && a.Wo <= 48)
+    rc = cw.stride == 1 ? launch_flat_dispatch<1>(cw.nf, a, cw.ntiles, stream, &handled)
+                        : launch_flat_dispatch<2>(cw.nf, a, cw.ntiles, stream, &handled);
   if (handled) {
   } else if (cw.ks == 3 && cw.stride == 1) rc = launch_nf<3, 1>(cw.nf, a, cw.ntiles, stream);
   else if (cw.ks == 3 && cw.stride == 2) rc = launch_nf<3, 2>(cw.nf, a, cw.ntiles, stream);

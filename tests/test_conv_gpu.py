@@ -51,6 +51,13 @@ CASES = [
     (2, 64, 64, 8, 16, 3, 2),     # stem (3 channels padded to 8)
     (1, 20, 20, 256, 256, 3, 2),
     (1, 9, 9, 144, 144, 3, 1),    # v8m-style widths
+    # flattened deep-K kernel: tiles cross rows and frame borders
+    (3, 20, 20, 128, 128, 3, 1),
+    (2, 40, 40, 128, 80, 3, 1),
+    (3, 40, 40, 128, 256, 3, 2),
+    (2, 21, 19, 136, 64, 3, 2),   # odd sizes, cin not a multiple of 32
+    (5, 5, 7, 128, 32, 3, 1),     # several frames inside one 128-pixel tile
+    (3, 7, 5, 160, 48, 3, 2),
 ]
 
 
