@@ -52,6 +52,8 @@ __device__ __forceinline__ int fast_div(int x, int d, float rd) {
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_f32(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
@@ -63,17 +65,19 @@ __device__ __forceinline__ float silu_f32(float v) {
 // caller preloaded them (persistent kernels: a global load inside the tile loop would drain the
 // in-order vmcnt queue and with it the next tile's prefetch); have_rpre = false loads it here.
 __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc, size_t opix, int c0, float4 b,
-                                           bool have_rpre = false, uint2 rpre = make_uint2(0, 0)) {
+                                           bool have_rpre = false, u32x2 rpre = u32x2{0, 0}) {
+  // native vector types throughout: arrays of the HIP uint2/uint4/__half structs end up in scratch memory
   if (c0 >= a.Cout) return;
-  float v[4] = {acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w};
+  float4v v = acc + float4v{b.x, b.y, b.z, b.w};
   if (a.act == kActSiLU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = silu_f32(v[j]);
   }
+  const bool full = c0 + 3 < a.Cout;
   if (a.out_f32) {
     float* o = a.out_f32 + opix * a.Cout + c0;
-    if (c0 + 3 < a.Cout && (a.Cout & 3) == 0) {
-      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    if (full && (a.Cout & 3) == 0) {
+      *reinterpret_cast<float4v*>(o) = v;
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -81,24 +85,21 @@ __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc
     }
     return;
   }
-  __half h[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) h[j] = __float2half_rn(v[j]);
-  if (c0 + 3 < a.Cout) {
+  f16x4 h = __builtin_convertvector(v, f16x4);  // RNE
+  if (full) {
     if (a.res) {
-      const uint2 r = have_rpre ? rpre : *reinterpret_cast<const uint2*>(a.res + opix * a.res_cs + c0);
-      const __half* rh = reinterpret_cast<const __half*>(&r);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) h[j] = __float2half_rn(__half2float(h[j]) + __half2float(rh[j]));
+      const u32x2 r = have_rpre ? rpre : *reinterpret_cast<const u32x2*>(a.res + opix * a.res_cs + c0);
+      const float4v sum = __builtin_convertvector(h, float4v) + __builtin_convertvector(__builtin_bit_cast(f16x4, r), float4v);
+      h = __builtin_convertvector(sum, f16x4);
     }
-    *reinterpret_cast<uint2*>(a.out + opix * a.out_cs + c0) = *reinterpret_cast<uint2*>(h);
+    *reinterpret_cast<u32x2*>(a.out + opix * a.out_cs + c0) = __builtin_bit_cast(u32x2, h);
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (c0 + j < a.Cout) {
-        __half o = h[j];
-        if (a.res) o = __float2half_rn(__half2float(o) + __half2float(a.res[opix * a.res_cs + c0 + j]));
-        a.out[opix * a.out_cs + c0 + j] = o;
+        _Float16 o = h[j];
+        if (a.res) o = (_Float16)((float)o + __half2float(a.res[opix * a.res_cs + c0 + j]));
+        reinterpret_cast<_Float16*>(a.out)[opix * a.out_cs + c0 + j] = o;
       }
   }
 }
@@ -471,53 +472,58 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
   constexpr int WT_U = TAPS * 16 * NF * 4;        // per chunk
   constexpr int NLOAD = PH * PW * 4 * NCH;        // staged units per tile
   constexpr int R = (NLOAD + 255) / 256;          // per thread
+  static_assert(R <= 32, "slot mask is one 32-bit word");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wt = reinterpret_cast<uint4*>(smem);                 // [NCH][WT_U]
-  uint4* patch = wt + NCH * WT_U;                             // [DB ? 2 : 1][NCH][PATCH_U]
+  uint4* patch = wt + NCH * WT_U;                             // [DB ? 2 : 1][NCH][PATCH_U] (+ 1 spare unit)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co_tile = blockIdx.y;
-  // per-thread staging slots: slot j -> (chunk, pixel, unit) is tile independent
-  int s_off[R];      // LDS unit index inside one patch buffer, or -1
+  // per-thread staging slots: slot j -> (chunk, pixel, unit) is tile independent.  The tile loop is branch-free:
+  // every slot loads (element 0 when it has nothing to fetch) and stores (to the spare unit when it maps to no
+  // patch position); padding is a select to zero at store time, skipped by whole waves on interior tiles.
+  int s_off[R];                    // LDS unit index inside one patch buffer (spare unit for unused slots)
   int s_py[R], s_px[R], s_rel[R];  // s_rel: element offset of the slot relative to the tile's (ih0, iw0) pixel
+  unsigned s_live = 0;             // bit j: slot j fetches (inside the patch and below Cin)
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int idx = tid + 256 * j;
-    s_off[j] = -1;
-    s_py[j] = s_px[j] = s_rel[j] = 0;
-    if (idx < NLOAD) {
-      const int cc = idx / (PH * PW * 4), rem = idx - cc * (PH * PW * 4);
-      const int pix = rem >> 2, unit = rem & 3;
-      const int py = pix / PW, px = pix - py * PW;
-      const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
-      const int p = py * PWS + col;
-      s_off[j] = cc * PATCH_U + p * 4 + (unit ^ ((p >> 1) & 3));
-      s_py[j] = py;
-      s_px[j] = px;
-      s_rel[j] = (py * a.W + px) * a.in_cs + cc * 32 + unit * 8;
-      if (cc * 32 + unit * 8 >= a.Cin) s_off[j] = -2 - s_off[j];  // zero-filled slot: still written, never loaded
-    }
+    const int cc = idx / (PH * PW * 4), rem = idx - cc * (PH * PW * 4);
+    const int pix = rem >> 2, unit = rem & 3;
+    const int py = pix / PW, px = pix - py * PW;
+    const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
+    const int p = py * PWS + col;
+    const bool in_patch = idx < NLOAD;
+    s_off[j] = in_patch ? cc * PATCH_U + p * 4 + (unit ^ ((p >> 1) & 3)) : (DB ? 2 : 1) * NCH * PATCH_U;
+    s_py[j] = py;
+    s_px[j] = px;
+    s_rel[j] = (py * a.W + px) * a.in_cs + cc * 32 + unit * 8;
+    if (in_patch && cc * 32 + unit * 8 < a.Cin) s_live |= 1u << j;
   }
   const int tiles_per_img = a.tiles_w * a.tiles_h;
-  uint4 stage[R];
+  const float r_tpi = 1.0f / (float)tiles_per_img, r_tw = 1.0f / (float)a.tiles_w;
+  u32x4 stage[R];
+  unsigned s_ok = 0;  // bit j: slot j of the staged tile holds fetched data (else zero padding)
+  int nx_n = 0, nx_th = 0, nx_tw = 0;  // coordinates of the staged tile
   auto issue = [&](int tile) {
-    const int n = tile / tiles_per_img, t2 = tile - n * tiles_per_img;
-    const int th = t2 / a.tiles_w, tw = t2 - th * a.tiles_w;
-    const int ih0 = th * kTH * S - PAD, iw0 = tw * kTW * S - PAD;
-    // (ih0, iw0) may lie outside the image: the base is only dereferenced through in-range slots
-    const __half* base = a.in + ((size_t)n * a.H * a.W + (long long)ih0 * a.W + iw0) * a.in_cs;
+    nx_n = fast_div(tile, tiles_per_img, r_tpi);
+    const int t2 = tile - nx_n * tiles_per_img;
+    nx_th = fast_div(t2, a.tiles_w, r_tw);
+    nx_tw = t2 - nx_th * a.tiles_w;
+    const int ih0 = nx_th * kTH * S - PAD, iw0 = nx_tw * kTW * S - PAD;
+    const int base = ((nx_n * a.H + ih0) * a.W + iw0) * a.in_cs;  // may be negative; only in-range slots use it
+    s_ok = 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const int ih = ih0 + s_py[j], iw = iw0 + s_px[j];
-      stage[j] = make_uint4(0, 0, 0, 0);
-      if (s_off[j] >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-        stage[j] = *reinterpret_cast<const uint4*>(base + s_rel[j]);
+      const bool ok = ((s_live >> j) & 1) && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      s_ok |= (ok ? 1u : 0u) << j;
+      stage[j] = *reinterpret_cast<const u32x4*>(a.in + (ok ? base + s_rel[j] : 0));
     }
   };
 
-  // B-fragment unit positions inside a chunk's patch: they depend on (lane, tap, m) only, so the swizzle
-  // arithmetic leaves the tile loop (it was ~2.5 VALU per MFMA on a VALU-issue-bound kernel)
+  // B-fragment unit positions inside a chunk's patch: they depend on (lane, tap, m) only
   int bpos[TAPS][2];
 #pragma unroll
   for (int tap = 0; tap < TAPS; ++tap)
@@ -529,6 +535,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
       const int p = py * PWS + col;
       bpos[tap][m] = p * 4 + ((lane >> 4) ^ ((p >> 1) & 3));
     }
+  const uint4* wt_lane = wt + (lane & 15) * 4 + ((lane >> 4) ^ ((lane >> 1) & 3));
   float4 biasr[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f)
@@ -540,26 +547,39 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
   {
     const uint4* wsrc = a.wgt + (size_t)co_tile * NCH * WT_U;
     constexpr int NW = NCH * WT_U;
-#pragma unroll 8
-    for (int idx = tid; idx < NW; idx += 256) {
-      const int row = (idx % WT_U) >> 2, unit = idx & 3;
-      wt[(idx & ~3) + (unit ^ ((row >> 1) & 3))] = wsrc[idx];
+    constexpr int WB = 8;  // loads in flight per thread
+    for (int i0 = 0; i0 < NW; i0 += 256 * WB) {
+      u32x4 w[WB];
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int idx = i0 + j * 256 + tid;
+        w[j] = *reinterpret_cast<const u32x4*>(wsrc + (idx < NW ? idx : 0));
+      }
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int idx = i0 + j * 256 + tid;
+        const int row = (idx % WT_U) >> 2, unit = idx & 3;
+        if (idx < NW) *reinterpret_cast<u32x4*>(wt + (idx & ~3) + (unit ^ ((row >> 1) & 3))) = w[j];
+      }
     }
   }
   int buf = 0;
   for (; tile < total_tiles; tile += gridDim.x) {
     uint4* pb = patch + (DB ? buf : 0) * (NCH * PATCH_U);
     if (!DB) __syncthreads();  // single buffer: every wave is done reading the previous tile
+    if (s_ok != s_live) {      // border tile (or channel tail): padding slots become zero
 #pragma unroll
-    for (int j = 0; j < R; ++j)
-      if (s_off[j] != -1) pb[s_off[j] >= 0 ? s_off[j] : -2 - s_off[j]] = stage[j];
+      for (int j = 0; j < R; ++j)
+        if (!((s_ok >> j) & 1)) stage[j] = u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) *reinterpret_cast<u32x4*>(pb + s_off[j]) = stage[j];
     __syncthreads();  // also orders the weight copy before the first tile
-    const int tn = tile / tiles_per_img, tt2 = tile - tn * tiles_per_img;
-    const int tth = tt2 / a.tiles_w, ttw = tt2 - tth * a.tiles_w;
+    const int tn = nx_n, tth = nx_th, ttw = nx_tw;
     const int ow = ttw * kTW + (lane & 15);
     // residual of THIS tile first, then the next tile's patch: the epilogue then waits only for the
     // older loads (vmcnt is in order) and the prefetch stays in flight across it
-    uint2 resv[2][NF];
+    u32x2 resv[2][NF];
     if (res_vec) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
@@ -569,13 +589,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           const int c0 = co_tile * 16 * NF + f * 16 + (lane >> 4) * 4;
-          resv[m][f] = make_uint2(0, 0);
-          if (ok && c0 + 3 < a.Cout) resv[m][f] = *reinterpret_cast<const uint2*>(a.res + opix * a.res_cs + c0);
+          resv[m][f] = *reinterpret_cast<const u32x2*>(a.res + opix * a.res_cs + (c0 + 3 < a.Cout ? c0 : 0));
         }
       }
     }
     const int next = tile + gridDim.x;
     if (next < total_tiles) issue(next);  // in flight during the MFMAs below
+    __builtin_amdgcn_sched_barrier(0);
 
     float4v acc[2][NF];
 #pragma unroll
@@ -583,26 +603,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
 #pragma unroll
       for (int f = 0; f < NF; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int cc = 0; cc < NCH; ++cc) {
-#pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        half8 bfrag[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          uint4 u = pb[cc * PATCH_U + bpos[tap][m]];
-          bfrag[m] = *reinterpret_cast<half8*>(&u);
-        }
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          const int row = tap * 16 * NF + f * 16 + (lane & 15);
-          uint4 u = wt[cc * WT_U + row * 4 + ((lane >> 4) ^ ((row >> 1) & 3))];
-          half8 afrag = *reinterpret_cast<half8*>(&u);
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-            acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag[m], acc[m][f], 0, 0, 0);
-        }
-      }
-    }
+    for (int cc = 0; cc < NCH; ++cc) mma_taps<NF, 2>(pb + cc * PATCH_U, wt_lane + cc * WT_U, bpos, acc);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const int oh = tth * kTH + wave * 2 + m;
@@ -620,7 +622,7 @@ template <int NF, int S, int NCH, bool DB>
 int launch_persist(const ConvArgs& a, int ntiles, hipStream_t stream) {
   constexpr int PH = (kTH - 1) * S + 3, PW = (kTW - 1) * S + 3;
   constexpr int PWS = (S == 2) ? 2 * ((PW + 1) / 2) : PW;
-  constexpr size_t lds = ((size_t)NCH * 9 * 16 * NF * 4 + (DB ? 2 : 1) * (size_t)NCH * PH * PWS * 4) * 16;
+  constexpr size_t lds = ((size_t)NCH * 9 * 16 * NF * 4 + (DB ? 2 : 1) * (size_t)NCH * PH * PWS * 4 + 1) * 16;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_persist<NF, S, NCH, DB>),
@@ -644,7 +646,7 @@ int launch_persist(const ConvArgs& a, int ntiles, hipStream_t stream) {
 size_t persist_lds(int nf, int s, int nch, bool db) {
   const int ph = (kTH - 1) * s + 3, pw = (kTW - 1) * s + 3;
   const int pws = s == 2 ? 2 * ((pw + 1) / 2) : pw;
-  return ((size_t)nch * 9 * 16 * nf * 4 + (db ? 2 : 1) * (size_t)nch * ph * pws * 4) * 16;
+  return ((size_t)nch * 9 * 16 * nf * 4 + (db ? 2 : 1) * (size_t)nch * ph * pws * 4 + 1) * 16;
 }
 
 template <int S>
