@@ -22,6 +22,7 @@ using namespace eioku;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm helpers: one wave per token row, H <= 1024, H % 64 == 0
@@ -76,9 +77,44 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ id
   wave_layernorm<16>(x, nv, H, g, b, eps, out + (size_t)t * H, lane);
 }
 
-__global__ __launch_bounds__(256) void k_add_ln(const float* __restrict__ a, const float* __restrict__ r, int T,
-                                                int H, const float* __restrict__ g, const float* __restrict__ b,
-                                                float eps, float* __restrict__ out) {
+// Fixed-width variant (H = 64*NV): every load of the row (up to 4 split-K planes, bias, residual) is issued
+// before the first add, so one token costs one memory round trip instead of NV x (nsplit + 2) dependent ones.
+template <int NV>
+__global__ __launch_bounds__(256) void k_add_ln_fixed(const float* __restrict__ a, int nsplit, const float* __restrict__ abias,
+                                                      const float* __restrict__ r, int T, const float* __restrict__ g,
+                                                      const float* __restrict__ b, float eps, float* __restrict__ out) {
+  constexpr int H = 64 * NV;
+  const int lane = threadIdx.x & 63;
+  const int t = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (t >= T) return;
+  float pl[4][NV], rv[NV], bv[NV];
+#pragma unroll
+  for (int sp = 0; sp < 4; ++sp) {
+    const int spc = sp < nsplit ? sp : nsplit - 1;  // planes past nsplit: re-read the last one, never added
+#pragma unroll
+    for (int i = 0; i < NV; ++i) pl[sp][i] = a[((size_t)spc * T + t) * H + lane + 64 * i];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    rv[i] = r[(size_t)t * H + lane + 64 * i];
+    bv[i] = abias ? abias[lane + 64 * i] : 0.f;
+  }
+  float x[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float v = pl[0][i];
+#pragma unroll
+    for (int sp = 1; sp < 4; ++sp)
+      if (sp < nsplit) v += pl[sp][i];
+    if (abias) v += bv[i];
+    x[i] = v + rv[i];
+  }
+  wave_layernorm<NV>(x, NV, H, g, b, eps, out + (size_t)t * H, lane);
+}
+
+__global__ __launch_bounds__(256) void k_add_ln(const float* __restrict__ a, int nsplit, const float* __restrict__ abias,
+                                                const float* __restrict__ r, int T, int H, const float* __restrict__ g,
+                                                const float* __restrict__ b, float eps, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int t = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (t >= T) return;
@@ -88,7 +124,11 @@ __global__ __launch_bounds__(256) void k_add_ln(const float* __restrict__ a, con
   for (int i = 0; i < 16; ++i)
     if (i < nv) {
       const int c = lane + 64 * i;
-      x[i] = a[(size_t)t * H + c] + r[(size_t)t * H + c];
+      // a = nsplit split-K partial planes of the producing GEMM (summed in plane order: deterministic) [+ its bias]
+      float v = a[(size_t)t * H + c];
+      for (int sp = 1; sp < nsplit; ++sp) v += a[((size_t)sp * T + t) * H + c];
+      if (abias) v += abias[c];
+      x[i] = v + r[(size_t)t * H + c];
     }
   wave_layernorm<16>(x, nv, H, g, b, eps, out + (size_t)t * H, lane);
 }
@@ -106,7 +146,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 template <int EPI, int BM, int BN>  // EPI 0: bias, 1: bias + GELU
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ C, int ldc,
-                                                     int M, int N, int K) {
+                                                     int M, int N, int K, int kchunks) {
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int RA = BM / 32, RW = BN / 32;  // staged rows per thread
   __shared__ __attribute__((aligned(16))) float4 sA[2][BM * 8];
@@ -126,32 +166,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
 
   // staging map: unit = tid & 7, rows (tid>>3) + 32*it
   const int sunit = tid & 7, srow = tid >> 3;
-  float4 ra[RA], rw[RW];
+  // native vector registers (arrays of the HIP float4 struct can land in scratch) and unconditional loads
+  // (rows clamped to M-1: the compiler then counts vmcnt instead of draining the queue at every use)
+  f32x4 ra[RA], rw[RW];
+  const int kc0 = blockIdx.z * kchunks;  // split-K: this workgroup owns chunks [kc0, kc0 + kchunks)
   auto issue = [&](int kc) {
 #pragma unroll
     for (int it = 0; it < RA; ++it) {
-      const int m = m0 + srow + 32 * it;
-      ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M) ra[it] = *reinterpret_cast<const float4*>(A + (size_t)m * lda + kc * kBK + sunit * 4);
+      int m = m0 + srow + 32 * it;
+      if (m >= M) m = M - 1;
+      ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + (kc0 + kc) * kBK + sunit * 4);
     }
 #pragma unroll
     for (int it = 0; it < RW; ++it)
-      rw[it] = *reinterpret_cast<const float4*>(W + (size_t)(n0 + srow + 32 * it) * K + kc * kBK + sunit * 4);
+      rw[it] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + srow + 32 * it) * K + (kc0 + kc) * kBK + sunit * 4);
   };
   auto commit = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < RA; ++it) {
       const int row = srow + 32 * it;
-      sA[buf][row * 8 + (sunit ^ ((row >> 1) & 7))] = ra[it];
+      *reinterpret_cast<f32x4*>(&sA[buf][row * 8 + (sunit ^ ((row >> 1) & 7))]) = ra[it];
     }
 #pragma unroll
     for (int it = 0; it < RW; ++it) {
       const int row = srow + 32 * it;
-      sW[buf][row * 8 + (sunit ^ ((row >> 1) & 7))] = rw[it];
+      *reinterpret_cast<f32x4*>(&sW[buf][row * 8 + (sunit ^ ((row >> 1) & 7))]) = rw[it];
     }
   };
 
-  const int nk = K / kBK;
+  const int nk = kchunks;
+  C += (size_t)blockIdx.z * M * ldc;  // split-K partial planes; the consumer (k_add_ln) sums them and adds the bias
   issue(0);
   commit(0);
   __syncthreads();
@@ -217,15 +261,31 @@ __global__ __launch_bounds__(1024) void k_attention(const float* __restrict__ qk
   float* sM = reinterpret_cast<float*>(sV + (size_t)S * 8);  // [S] 1/0
   const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
   const size_t row0 = (size_t)b * S;
-  for (int i = tid; i < S * 8; i += blockDim.x) {
-    const int j = i >> 3, u = i & 7;
-    const float* base = qkv + (row0 + j) * (size_t)(3 * H) + h * 32 + u * 4;
-    sK[i] = *reinterpret_cast<const float4*>(base + H);
-    sV[i] = *reinterpret_cast<const float4*>(base + 2 * H);
+  // K and V rows of this (segment, head) -> LDS, 4 + 4 loads in flight per thread
+  for (int i0 = 0; i0 < S * 8; i0 += 4 * blockDim.x) {
+    f32x4 kk[4], vv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int i = i0 + t * blockDim.x + tid;
+      if (i >= S * 8) i = S * 8 - 1;
+      const float* base = qkv + (row0 + (i >> 3)) * (size_t)(3 * H) + h * 32 + (i & 7) * 4;
+      kk[t] = *reinterpret_cast<const f32x4*>(base + H);
+      vv[t] = *reinterpret_cast<const f32x4*>(base + 2 * H);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = i0 + t * blockDim.x + tid;
+      if (i < S * 8) {
+        *reinterpret_cast<f32x4*>(&sK[i]) = kk[t];
+        *reinterpret_cast<f32x4*>(&sV[i]) = vv[t];
+      }
+    }
   }
   for (int j = tid; j < S; j += blockDim.x) sM[j] = mask[row0 + j] ? 1.f : 0.f;
   __syncthreads();
-  const int qi = tid / PARTS, part = tid % PARTS;
+  // queries are split over blockIdx.z as well: (segment, head) alone is B x heads ~ 100 workgroups for a batch
+  // of 8 segments, a third of the chip
+  const int qi = blockIdx.z * (blockDim.x / PARTS) + tid / PARTS, part = tid % PARTS;
   const bool live = qi < S;  // lanes of a query group stay together for the shuffles below
   float q[32];
   {
@@ -236,7 +296,7 @@ __global__ __launch_bounds__(1024) void k_attention(const float* __restrict__ qk
       q[u * 4] = v.x; q[u * 4 + 1] = v.y; q[u * 4 + 2] = v.z; q[u * 4 + 3] = v.w;
     }
   }
-  const float inv = 5.65685424949238f;  // sqrt(32): scores / sqrt(head_size)
+  const float rinv = 0.17677669529663687f;  // 1 / sqrt(32): scores / sqrt(head_size)
   auto score = [&](int j) {
     float s = 0.f;
 #pragma unroll
@@ -247,7 +307,7 @@ __global__ __launch_bounds__(1024) void k_attention(const float* __restrict__ qk
       s += q[u * 4 + 2] * k.z;
       s += q[u * 4 + 3] * k.w;
     }
-    return s / inv;
+    return s * rinv;
   };
   float mx = -INFINITY;
   for (int j = part; j < S; j += PARTS)
@@ -292,11 +352,20 @@ __global__ __launch_bounds__(1024) void k_pool_norm(const float* __restrict__ x,
   __shared__ float red[16];
   const int b = blockIdx.x, c = threadIdx.x;
   float s = 0.f, cnt = 0.f;
-#pragma unroll 8
-  for (int t = 0; t < S; ++t) {
-    const float m = mask[(size_t)b * S + t] ? 1.f : 0.f;
-    cnt += m;
-    if (c < H) s += x[((size_t)b * S + t) * H + c] * m;
+  const int cc = c < H ? c : H - 1;  // loads stay unconditional: 8 tokens in flight per thread, summed in token order
+  for (int t0 = 0; t0 < S; t0 += 8) {
+    float xv[8], mv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = t0 + i < S ? t0 + i : S - 1;
+      mv[i] = (t0 + i < S && mask[(size_t)b * S + t]) ? 1.f : 0.f;
+      xv[i] = x[((size_t)b * S + t) * H + cc];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      cnt += mv[i];
+      s += xv[i] * mv[i];
+    }
   }
   const float v = c < H ? s / fmaxf(cnt, 1e-9f) : 0.f;
   float sq = v * v;
@@ -363,18 +432,44 @@ int find(const eioku_bert* m, const std::string& name) {
 
 const float* tp(const eioku_bert* m, const std::string& name) { return m->tensors[find(m, name)].dev; }
 
+constexpr int kMaxSplit = 4;
+
+void launch_add_ln(const float* a, int nsplit, const float* abias, const float* r, int T, int H, const float* g,
+                   const float* b, float eps, float* out, hipStream_t stream) {
+  const dim3 grid((unsigned)(((size_t)T * 64 + 255) / 256)), block(256);
+  if (H == 384) hipLaunchKernelGGL(k_add_ln_fixed<6>, grid, block, 0, stream, a, nsplit, abias, r, T, g, b, eps, out);
+  else if (H == 768) hipLaunchKernelGGL(k_add_ln_fixed<12>, grid, block, 0, stream, a, nsplit, abias, r, T, g, b, eps, out);
+  else hipLaunchKernelGGL(k_add_ln, grid, block, 0, stream, a, nsplit, abias, r, T, H, g, b, eps, out);
+}
+
+// Split-K factor for the two GEMMs that feed k_add_ln (N = hidden): with M = a few hundred tokens a 64x64 tiling
+// of an [M x 384] output is ~100 workgroups on 256 CUs, each walking all of K serially; `splits` planes of
+// partial sums (summed, in plane order, by k_add_ln) put 2-4x as many workgroups on the chip.
+int pick_splits(int M, int N, int K) {
+  if (M >= 8192) return 1;
+  const int blocks = ((M + 63) / 64) * (N / 64);
+  int s = 1;
+  while (s < kMaxSplit && blocks * s < 2 * num_cus() && (K / kBK) % (2 * s) == 0) s *= 2;
+  return s;
+}
+
+// C = A . W^T (+ bias, + GELU when epi == 1).  splits > 1: C receives `splits` partial planes [splits][M][ldc]
+// WITHOUT bias (epi must be 0); the consumer adds them up.
 int gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int epi,
-         hipStream_t stream) {
+         int splits, hipStream_t stream) {
   EIOKU_REQUIRE(N % 128 == 0 && K % kBK == 0, "gemm shape N=%d K=%d must be multiples of 128 / 32", N, K);
+  EIOKU_REQUIRE(splits >= 1 && (K / kBK) % splits == 0 && (splits == 1 || epi == 0), "bad split-K %d", splits);
+  const int kchunks = K / kBK / splits;
+  if (splits > 1) bias = nullptr;
   prof_start(EIOKU_PROF_GEMM, stream);
   if (M >= 8192) {
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)(N / 128));
-    if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
-    else hipLaunchKernelGGL((k_gemm_f32<0, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)(N / 128), (unsigned)splits);
+    if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
+    else hipLaunchKernelGGL((k_gemm_f32<0, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
   } else {
-    dim3 grid((unsigned)((M + 63) / 64), (unsigned)(N / 64));
-    if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1, 64, 64>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
-    else hipLaunchKernelGGL((k_gemm_f32<0, 64, 64>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K);
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)(N / 64), (unsigned)splits);
+    if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1, 64, 64>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
+    else hipLaunchKernelGGL((k_gemm_f32<0, 64, 64>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
   }
   prof_stop(EIOKU_PROF_GEMM, stream);
   EIOKU_LAUNCH_CHECK();
@@ -517,7 +612,7 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
     d_out = m->d_out;
   }
   if ((rc = grow(&m->x, &m->x_cap, (size_t)T * H * 4))) return rc;
-  if ((rc = grow(&m->y, &m->y_cap, (size_t)T * H * 4))) return rc;
+  if ((rc = grow(&m->y, &m->y_cap, (size_t)kMaxSplit * T * H * 4))) return rc;
   if ((rc = grow(&m->ctx, &m->ctx_cap, (size_t)T * H * 4))) return rc;
   if ((rc = grow(&m->qkv, &m->qkv_cap, (size_t)T * 3 * H * 4))) return rc;
   if ((rc = grow(&m->mid, &m->mid_cap, (size_t)T * m->ffn * 4))) return rc;
@@ -529,7 +624,8 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
                      tp(m, "embeddings.LayerNorm.bias"), m->eps, m->x);
   EIOKU_LAUNCH_CHECK();
   const int parts = S <= 256 ? 4 : 1;
-  const int athreads = ((S * parts + 63) / 64) * 64;
+  const int qsplit = parts == 4 ? (S + 31) / 32 : 1;  // 32 queries x 4 lanes = 2 waves per workgroup
+  const int athreads = parts == 4 ? 128 : ((S + 63) / 64) * 64;
   const size_t alds = (size_t)S * 8 * 16 * 2 + (size_t)S * 4;
   if (alds > 64 * 1024) {
     static bool attr = false;
@@ -542,24 +638,25 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
   for (int l = 0; l < m->L; ++l) {
     const std::string p = "encoder.layer." + std::to_string(l) + ".";
     if ((rc = gemm(m->x, H, tp(m, p + "attention.self.query.weight"), tp(m, p + "attention.self.query.bias"), m->qkv,
-                   3 * H, T, 3 * H, H, 0, stream))) return rc;
+                   3 * H, T, 3 * H, H, 0, 1, stream))) return rc;
     if (parts == 4)
-      hipLaunchKernelGGL(k_attention<4>, dim3(B, m->heads), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
+      hipLaunchKernelGGL(k_attention<4>, dim3(B, m->heads, qsplit), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
     else
       hipLaunchKernelGGL(k_attention<1>, dim3(B, m->heads), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
     EIOKU_LAUNCH_CHECK();
+    const int sp_o = pick_splits(T, H, H), sp_f = pick_splits(T, H, m->ffn);
     if ((rc = gemm(m->ctx, H, tp(m, p + "attention.output.dense.weight"), tp(m, p + "attention.output.dense.bias"), m->y,
-                   H, T, H, H, 0, stream))) return rc;
-    hipLaunchKernelGGL(k_add_ln, dim3(tok_blocks), dim3(256), 0, stream, m->y, m->x, T, H,
+                   H, T, H, H, 0, sp_o, stream))) return rc;
+    launch_add_ln(m->y, sp_o, sp_o > 1 ? tp(m, p + "attention.output.dense.bias") : nullptr, m->x, T, H,
                        tp(m, p + "attention.output.LayerNorm.weight"), tp(m, p + "attention.output.LayerNorm.bias"),
-                       m->eps, m->x);
+                       m->eps, m->x, stream);
     EIOKU_LAUNCH_CHECK();
     if ((rc = gemm(m->x, H, tp(m, p + "intermediate.dense.weight"), tp(m, p + "intermediate.dense.bias"), m->mid, m->ffn,
-                   T, m->ffn, H, 1, stream))) return rc;
+                   T, m->ffn, H, 1, 1, stream))) return rc;
     if ((rc = gemm(m->mid, m->ffn, tp(m, p + "output.dense.weight"), tp(m, p + "output.dense.bias"), m->y, H, T, H,
-                   m->ffn, 0, stream))) return rc;
-    hipLaunchKernelGGL(k_add_ln, dim3(tok_blocks), dim3(256), 0, stream, m->y, m->x, T, H,
-                       tp(m, p + "output.LayerNorm.weight"), tp(m, p + "output.LayerNorm.bias"), m->eps, m->x);
+                   m->ffn, 0, sp_f, stream))) return rc;
+    launch_add_ln(m->y, sp_f, sp_f > 1 ? tp(m, p + "output.dense.bias") : nullptr, m->x, T, H,
+                       tp(m, p + "output.LayerNorm.weight"), tp(m, p + "output.LayerNorm.bias"), m->eps, m->x, stream);
     EIOKU_LAUNCH_CHECK();
   }
   const int pthreads = ((H + 63) / 64) * 64;

@@ -117,31 +117,52 @@ __global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
   constexpr int ROWS = 16 * NF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co_tile = blockIdx.y;
-  const uint4* wsrc = a.wgt + (size_t)co_tile * a.nchunks * (ROWS * 4);
-  for (int idx = tid; idx < a.nchunks * ROWS * 4; idx += 256) {
-    const int row = (idx >> 2) % ROWS, unit = idx & 3;
-    wt[(idx & ~3) + (unit ^ ((row >> 1) & 3))] = wsrc[idx];
+  {
+    // weight tile -> LDS, 8 loads in flight per thread (one load -> one store per iteration made this copy the
+    // longest phase of the low-resolution layers: 24 dependent round trips for Cin = 384)
+    const uint4* wsrc = a.wgt + (size_t)co_tile * a.nchunks * (ROWS * 4);
+    const int NW = a.nchunks * ROWS * 4;
+    constexpr int WB = 8;
+    for (int i0 = 0; i0 < NW; i0 += 256 * WB) {
+      u32x4 w[WB];
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int idx = i0 + j * 256 + tid;
+        w[j] = *reinterpret_cast<const u32x4*>(wsrc + (idx < NW ? idx : 0));
+      }
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int idx = i0 + j * 256 + tid;
+        const int row = (idx >> 2) % ROWS, unit = idx & 3;
+        if (idx < NW) *reinterpret_cast<u32x4*>(wt + (idx & ~3) + (unit ^ ((row >> 1) & 3))) = w[j];
+      }
+    }
   }
   __syncthreads();
 
   const int r = lane & 15, u = lane >> 4;
+  const uint4* wt_lane = wt + r * 4 + (u ^ ((r >> 1) & 3));  // fragment (kc, f): + (kc*NF + f)*64 units
   const long long groups = (npix + 31) / 32;  // 32 pixels (2 fragments) per wave step
   const long long gstride = (long long)gridDim.x * 4;
   long long g = (long long)blockIdx.x * 4 + wave;
 
-  // B fragments are fetched KB k-steps (KB x 2 x 16 B per lane) at a time, one block ahead of the MFMAs:
-  // with few waves per CU (low-resolution layers) a one-step lookahead leaves every step waiting on L2/HBM.
+  // B fragments are fetched KB k-steps (KB x 2 x 16 B per lane) at a time, one block ahead of the MFMAs.  The
+  // loads are unconditional (pixel and chunk indices clamped into the tensor) so that the compiler counts them
+  // (vmcnt(N)) instead of draining the queue, prefetch included, before every k-step.
   constexpr int KB = 4;
   const int nkb = (a.nchunks + KB - 1) / KB;
-  auto load_blk = [&](long long grp, int kb, uint4 (&b)[KB][2]) {
+  const bool cin_tail = (a.Cin & 31) != 0;
+  auto load_blk = [&](long long grp, int kb, u32x4 (&b)[KB][2]) {
 #pragma unroll
-    for (int j = 0; j < KB; ++j) {
-      const int c = (kb * KB + j) * 32 + u * 8;
+    for (int m = 0; m < 2; ++m) {
+      long long p = grp * 32 + m * 16 + r;
+      if (p >= npix) p = npix - 1;
+      const __half* src = a.in + (size_t)p * a.in_cs + u * 8;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const long long p = grp * 32 + m * 16 + r;
-        b[j][m] = make_uint4(0, 0, 0, 0);
-        if (p < npix && c < a.Cin) b[j][m] = *reinterpret_cast<const uint4*>(a.in + (size_t)p * a.in_cs + c);
+      for (int j = 0; j < KB; ++j) {
+        int c = (kb * KB + j) * 32;
+        if (c + u * 8 >= a.Cin) c = 0;  // past Cin: any in-range address; zeroed below / never multiplied
+        b[j][m] = *reinterpret_cast<const u32x4*>(src + c);
       }
     }
   };
@@ -149,7 +170,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
   float4 biasr[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) biasr[f] = *reinterpret_cast<const float4*>(a.bias + co_tile * ROWS + f * 16 + u * 4);
-  uint4 bn[KB][2];
+  u32x4 bn[KB][2];
   if (g < groups) load_blk(g, 0, bn);
   for (; g < groups; g += gstride) {
     float4v acc[2][NF];
@@ -158,29 +179,38 @@ __global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
     for (int kb = 0; kb < nkb; ++kb) {
-      uint4 b[KB][2];
+      u32x4 b[KB][2];
 #pragma unroll
       for (int j = 0; j < KB; ++j) {
         b[j][0] = bn[j][0];
         b[j][1] = bn[j][1];
       }
+      if (cin_tail && kb == nkb - 1) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+          if ((kb * KB + j) * 32 + u * 8 >= a.Cin) b[j][0] = b[j][1] = u32x4{0, 0, 0, 0};
+      }
       if (kb + 1 < nkb) load_blk(g, kb + 1, bn);
       else if (g + gstride < groups) load_blk(g + gstride, 0, bn);  // next group's first block in flight
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < KB; ++j) {
         const int kc = kb * KB + j;
         if (kc < a.nchunks) {
+          half8 af[NF];
 #pragma unroll
           for (int f = 0; f < NF; ++f) {
-            const int row = f * 16 + r;
-            uint4 w = wt[(kc * ROWS + row) * 4 + (u ^ ((row >> 1) & 3))];
-            half8 afrag = *reinterpret_cast<half8*>(&w);
+            uint4 w = wt_lane[(kc * NF + f) * 64];
+            af[f] = *reinterpret_cast<half8*>(&w);
+          }
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
-              acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, *reinterpret_cast<half8*>(&b[j][m]), acc[m][f], 0, 0, 0);
-          }
+              acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], __builtin_bit_cast(half8, b[j][m]), acc[m][f], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
