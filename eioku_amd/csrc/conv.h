@@ -41,8 +41,18 @@ enum ConvAct { kActNone = 0, kActSiLU = 1 };
 // out = act(conv(in) + bias) [+ res]; output fp16 into `out`, or fp32 into `out_f32` (dense
 // [N,Ho,Wo,cout]) when out_f32 != nullptr.  H, W: input size; output is ceil-free standard
 // (H + 2*pad - ks)/stride + 1 with pad = ks/2.
+// `fused` (stem only: k=3, s=2, Cin=8): the input is not a tensor but K3's letterbox of a BGR u8 batch, evaluated
+// inside the kernel's staging loads (mode 0 = copy, 2 = exact 1/2 area; H, W = letterboxed size); `in` is ignored.
+struct FusedInput {
+  const uint8_t* bgr;   // device, [N][src_h][src_w][3]
+  int src_h, src_w;     // original frame
+  int new_h, new_w;     // resized (unpadded) size
+  int top, left;        // padding offsets
+  int mode;             // LetterboxPlan::mode, 0 or 2
+};
+bool fused_input_ok(const ConvWeights& cw, const FusedInput& f, Slice res, const float* out_f32);
 int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out, float* out_f32,
-                 Slice res, int act, hipStream_t stream);
+                 Slice res, int act, hipStream_t stream, const FusedInput* fused = nullptr);
 
 inline int conv_out_dim(int x, int ks, int stride) { return (x + 2 * (ks / 2) - ks) / stride + 1; }
 

@@ -648,6 +648,216 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stem variant (Cin = 8: RGB + 5 zero channels, stride 2).  The generic kernels pad the 8 channels to a
+// 32-channel chunk (3/4 of every MFMA and of every LDS byte is zero); here the K axis of a chunk is
+// 4 TAPS x 8 channels instead: lane group q of a B fragment reads the pixel of tap 4j+q, so the 3x3
+// window is 3 MFMA k-steps instead of 9 and the LDS patch holds one 16-byte unit per pixel.
+// SRC 0: fp16 NHWC input.  SRC 1 / 2: the letterboxed network input never exists in memory -- the
+// staging slots read the BGR u8 frame (copy / exact 1/2 area modes of K3, same integer arithmetic,
+// same fp16 rounding of v/255, 114 grey outside the image) and build the unit on the way to LDS.
+// ---------------------------------------------------------------------------------------------
+struct FusedSrc {
+  const uint8_t* bgr;
+  int src_h, src_w, new_h, new_w, top, left;
+};
+
+template <int NF, int S, int SRC>
+__global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int total_tiles) {
+  constexpr int KS = 3, PAD = 1;
+  constexpr int PH = (kTH - 1) * S + KS;
+  constexpr int PW = (kTW - 1) * S + KS;
+  constexpr int PWH = (PW + 1) / 2;
+  constexpr int PWS = (S == 2) ? 2 * PWH : PW;
+  constexpr int PATCH_U = PH * PWS + 1;  // one unit per pixel (+ spare for idle slots)
+  constexpr int NPIX = PH * PW;
+  constexpr int R = (NPIX + 255) / 256;
+  constexpr int ROWS = 16 * NF;
+  constexpr int NB = SRC == 0 ? 1 : (SRC == 1 ? 3 : 12);  // raw registers per slot
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* wt = reinterpret_cast<uint4*>(smem);  // [3 k-steps][ROWS][4 taps] swizzled per row
+  uint4* patch = wt + 3 * ROWS * 4;            // [2][PATCH_U]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co_tile = blockIdx.y;
+  {
+    const uint4* wsrc = a.wgt + (size_t)co_tile * (9 * ROWS * 4);  // packed [tap][row][4 units]; unit 0 = channels 0..7
+    for (int idx = tid; idx < 3 * ROWS * 4; idx += 256) {
+      const int j = idx / (ROWS * 4), row = (idx >> 2) % ROWS, q = idx & 3;
+      const int tap = 4 * j + q;
+      u32x4 v = u32x4{0, 0, 0, 0};
+      if (tap < 9) v = *reinterpret_cast<const u32x4*>(wsrc + (tap * ROWS + row) * 4);
+      *reinterpret_cast<u32x4*>(wt + (idx & ~3) + (q ^ ((row >> 1) & 3))) = v;
+    }
+  }
+  int s_off[R], s_py[R], s_px[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int idx = tid + 256 * j;
+    const int py = idx / PW, px = idx - py * PW;
+    const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
+    s_off[j] = idx < NPIX ? py * PWS + col : PATCH_U - 1;
+    s_py[j] = py;
+    s_px[j] = px;
+  }
+  const int tiles_per_img = a.tiles_w * a.tiles_h;
+  const float r_tpi = 1.0f / (float)tiles_per_img, r_tw = 1.0f / (float)a.tiles_w;
+  u32x4 stage[SRC == 0 ? R : 1];
+  unsigned raw[SRC == 0 ? 1 : R][NB];
+  unsigned s_in = 0, s_img = 0;  // bit j: slot inside the network input / inside the image (fused modes)
+  int nx_n = 0, nx_th = 0, nx_tw = 0;
+  auto issue = [&](int tile) {
+    nx_n = fast_div(tile, tiles_per_img, r_tpi);
+    const int t2 = tile - nx_n * tiles_per_img;
+    nx_th = fast_div(t2, a.tiles_w, r_tw);
+    nx_tw = t2 - nx_th * a.tiles_w;
+    const int ih0 = nx_th * kTH * S - PAD, iw0 = nx_tw * kTW * S - PAD;
+    s_in = 0;
+    s_img = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int ih = ih0 + s_py[j], iw = iw0 + s_px[j];
+      const bool in = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      s_in |= (in ? 1u : 0u) << j;
+      if (SRC == 0) {
+        stage[j] = *reinterpret_cast<const u32x4*>(a.in + (in ? ((size_t)(nx_n * a.H + ih) * a.W + iw) * a.in_cs : 0));
+      } else {
+        const int y = ih - fs.top, x = iw - fs.left;
+        const bool img = in && (unsigned)y < (unsigned)fs.new_h && (unsigned)x < (unsigned)fs.new_w;
+        s_img |= (img ? 1u : 0u) << j;
+        const uint8_t* f = fs.bgr + (size_t)nx_n * fs.src_h * fs.src_w * 3;
+        if (SRC == 1) {
+          const uint8_t* p = f + (img ? ((size_t)y * fs.src_w + x) * 3 : 0);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) raw[j][c] = p[c];
+        } else {
+          const uint8_t* p0 = f + (img ? ((size_t)(2 * y) * fs.src_w + 2 * x) * 3 : 0);
+          const uint8_t* p1 = p0 + (img ? (size_t)fs.src_w * 3 : 0);
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            raw[j][c] = p0[c];
+            raw[j][6 + c] = p1[c];
+          }
+        }
+      }
+    }
+  };
+  auto unit_of = [&](int j) -> u32x4 {
+    if (SRC == 0) {
+      return ((s_in >> j) & 1) ? stage[j] : u32x4{0, 0, 0, 0};
+    } else {
+      int v[3] = {114, 114, 114};
+      if ((s_img >> j) & 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          v[c] = SRC == 1 ? (int)raw[j][c] : (int)((raw[j][c] + raw[j][c + 3] + raw[j][6 + c] + raw[j][9 + c] + 2) >> 2);
+      }
+      // BGR -> RGB, /255 in fp32, fp16 RNE: exactly K3's arithmetic
+      f16x4 lo = f16x4{(_Float16)((float)v[2] / 255.0f), (_Float16)((float)v[1] / 255.0f), (_Float16)((float)v[0] / 255.0f),
+                       (_Float16)0.f};
+      u32x2 l2 = __builtin_bit_cast(u32x2, lo);
+      u32x4 u = u32x4{l2[0], l2[1], 0, 0};
+      return ((s_in >> j) & 1) ? u : u32x4{0, 0, 0, 0};
+    }
+  };
+
+  // B-fragment positions: lane group q = lane>>4 reads the pixel of tap 4j+q (taps >= 9: weights are zero)
+  int bpos[3][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      int tap = 4 * j + (lane >> 4);
+      if (tap > 8) tap = 8;
+      const int py = (wave * 2 + m) * S + tap / KS;
+      const int px = (lane & 15) * S + tap % KS;
+      const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
+      bpos[j][m] = py * PWS + col;
+    }
+  const uint4* wt_lane = wt + (lane & 15) * 4 + ((lane >> 4) ^ ((lane >> 1) & 3));
+  float4 biasr[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+    biasr[f] = *reinterpret_cast<const float4*>(a.bias + co_tile * ROWS + f * 16 + (lane >> 4) * 4);
+
+  int tile = blockIdx.x;
+  if (tile < total_tiles) issue(tile);
+  int buf = 0;
+  for (; tile < total_tiles; tile += gridDim.x) {
+    uint4* pb = patch + buf * PATCH_U;
+#pragma unroll
+    for (int j = 0; j < R; ++j) *reinterpret_cast<u32x4*>(pb + s_off[j]) = unit_of(j);
+    __syncthreads();  // double-buffered patch: one barrier per tile (also orders the weight copy before tile 0)
+    const int tn = nx_n, tth = nx_th, ttw = nx_tw;
+    const int next = tile + gridDim.x;
+    if (next < total_tiles) issue(next);
+    __builtin_amdgcn_sched_barrier(0);
+
+    float4v acc[2][NF];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      half8 bf[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        uint4 u = pb[bpos[j][m]];
+        bf[m] = *reinterpret_cast<half8*>(&u);
+      }
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        uint4 w = wt_lane[(j * NF + f) * 64];
+        const half8 af = *reinterpret_cast<half8*>(&w);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[m], acc[m][f], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int ow = ttw * kTW + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int oh = tth * kTH + wave * 2 + m;
+      if (oh >= a.Ho || ow >= a.Wo) continue;
+      const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) store_frag(a, acc[m][f], opix, co_tile * ROWS + f * 16 + (lane >> 4) * 4, biasr[f]);
+    }
+    buf ^= 1;
+  }
+}
+
+template <int NF, int S, int SRC>
+int launch_c8(const ConvArgs& a, const FusedSrc& fs, int ntiles, hipStream_t stream) {
+  constexpr int PH = (kTH - 1) * S + 3, PW = (kTW - 1) * S + 3;
+  constexpr int PWS = (S == 2) ? 2 * ((PW + 1) / 2) : PW;
+  constexpr size_t lds = ((size_t)3 * 16 * NF * 4 + 2 * (PH * PWS + 1)) * 16;
+  const int total = a.tiles_w * a.tiles_h * a.N;
+  int bx = num_cus() * 6 / ntiles;  // small LDS footprint: ~6 workgroups per CU keep the byte loads in flight
+  if (bx < 1) bx = 1;
+  if (bx > total) bx = total;
+  hipLaunchKernelGGL((k_conv3x3_c8<NF, S, SRC>), dim3((unsigned)bx, (unsigned)ntiles), dim3(256), lds, stream, a, fs, total);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+template <int S>
+int launch_c8_dispatch(int nf, int src, const ConvArgs& a, const FusedSrc& fs, int ntiles, hipStream_t stream, bool* handled) {
+  *handled = true;
+#define EIOKU_C8(NF_)                                                            \
+  if (nf == NF_) {                                                                \
+    if (src == 0) return launch_c8<NF_, S, 0>(a, fs, ntiles, stream);              \
+    if (src == 1) return launch_c8<NF_, S, 1>(a, fs, ntiles, stream);              \
+    return launch_c8<NF_, S, 2>(a, fs, ntiles, stream);                            \
+  }
+  EIOKU_C8(1) EIOKU_C8(2) EIOKU_C8(3) EIOKU_C8(4) EIOKU_C8(5)
+#undef EIOKU_C8
+  *handled = false;
+  return EIOKU_OK;
+}
+
 template <int NF, int S, int NCH, bool DB>
 int launch_persist(const ConvArgs& a, int ntiles, hipStream_t stream) {
   constexpr int PH = (kTH - 1) * S + 3, PW = (kTW - 1) * S + 3;
@@ -901,10 +1111,16 @@ void conv_weights_destroy(ConvWeights* cw) {
   cw->d_b = nullptr;
 }
 
+bool fused_input_ok(const ConvWeights& cw, const FusedInput& f, Slice res, const float* out_f32) {
+  return cw.ks == 3 && cw.cin == 8 && cw.stride == 2 && cw.nf <= 5 && !res.ptr && !out_f32 && (f.mode == 0 || f.mode == 2) &&
+         f.bgr != nullptr;
+}
+
 int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out, float* out_f32,
-                 Slice res, int act, hipStream_t stream) {
+                 Slice res, int act, hipStream_t stream, const FusedInput* fused) {
   EIOKU_REQUIRE(cw.d_w, "conv weights not created");
-  EIOKU_REQUIRE(in.ptr && (out.ptr || out_f32), "NULL tensor");
+  EIOKU_REQUIRE((in.ptr || fused) && (out.ptr || out_f32), "NULL tensor");
+  EIOKU_REQUIRE(!fused || fused_input_ok(cw, *fused, res, out_f32), "layer cannot read a fused letterbox input");
   EIOKU_REQUIRE(in.cstride % 8 == 0 && in.coff % 8 == 0, "input slice must be 8-channel aligned");
   // cout < 4 (the 1-class face head) only ever takes the scalar store path
   EIOKU_REQUIRE(out_f32 || cw.cout < 4 || (out.cstride % 4 == 0 && out.coff % 4 == 0),
@@ -913,7 +1129,7 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
                 "residual slice must be 4-channel aligned");
   if (N == 0) return EIOKU_OK;
   ConvArgs a;
-  a.in = in.ptr + in.coff;
+  a.in = in.ptr ? in.ptr + in.coff : nullptr;
   a.wgt = reinterpret_cast<const uint4*>(cw.d_w);
   a.bias = cw.d_b;
   a.out = out.ptr ? out.ptr + out.coff : nullptr;
@@ -936,7 +1152,21 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
   prof_start(EIOKU_PROF_CONV, stream);
   int rc = EIOKU_OK;
   bool handled = false;
-  if (cw.ks == 3 && cw.nchunks <= 3) {
+  if (cw.ks == 3 && cw.cin == 8 && cw.stride == 2 && !res.ptr && !out_f32) {
+    FusedSrc fs{};
+    int src = 0;
+    if (fused) {
+      fs = FusedSrc{fused->bgr, fused->src_h, fused->src_w, fused->new_h, fused->new_w, fused->top, fused->left};
+      src = fused->mode == 0 ? 1 : 2;
+    }
+    rc = launch_c8_dispatch<2>(cw.nf, src, a, fs, cw.ntiles, stream, &handled);
+  }
+  if (!handled && fused) {
+    set_error("no fused-input kernel for this stem (nf %d)", cw.nf);
+    rc = EIOKU_EINVAL;
+    handled = true;
+  }
+  if (!handled && cw.ks == 3 && cw.nchunks <= 3) {
     // double-buffer the patch only when that still leaves two workgroups per CU
     const bool db = persist_lds(cw.nf, cw.stride, cw.nchunks, true) <= 75 * 1024;
     if (persist_lds(cw.nf, cw.stride, cw.nchunks, db) <= 150 * 1024)

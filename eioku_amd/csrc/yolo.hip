@@ -16,6 +16,8 @@
 
 #include "yolo_ops.h"
 
+#include <cstdlib>
+
 using namespace eioku;
 
 namespace {
@@ -236,7 +238,7 @@ int prepare(eioku_yolo* y, int n, int h, int w) {
   return EIOKU_OK;
 }
 
-int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream) {
+int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedInput* fused = nullptr) {
   for (size_t i = 0; i < y->set.size(); ++i)
     EIOKU_REQUIRE(y->set[i], "conv %zu (%s) has no weights", i, y->names[i].c_str());
   double flops = 0;
@@ -256,7 +258,8 @@ int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream) {
         out = Slice{ob.ptr, ob.ch, op.out_off};
       }
       if (op.res_buf >= 0) res = Slice{y->bufs[op.res_buf].ptr, y->bufs[op.res_buf].ch, op.res_off};
-      rc = conv_forward(cw, in, n, H, W, out, f32, res, op.act, stream);
+      const bool first = &op == &y->ops.front();
+      rc = conv_forward(cw, in, n, H, W, out, f32, res, op.act, stream, first ? fused : nullptr);
       flops += cw.flops_per_pixel() * n * conv_out_dim(H, cw.ks, cw.stride) * conv_out_dim(W, cw.ks, cw.stride);
     } else if (op.kind == kPool) {
       const Buf& ob = y->bufs[op.out_buf];
@@ -412,9 +415,18 @@ int eioku_yolo_detect(eioku_yolo* y, const uint8_t* bgr, int n, int h, int w, co
     EIOKU_HIP_CHECK(hipMemcpyAsync(s, bgr, (size_t)n * h * w * 3, hipMemcpyHostToDevice, stream));
     d_bgr = s;
   }
-  rc = letterbox_forward(d_bgr, n, p, y->bufs[y->in_buf].ptr, stream);
-  if (rc) return rc;
-  rc = run_network(y, n, p.out_h, p.out_w, stream);
+  // copy / exact-half letterbox modes: the stem reads the frames itself (the fp16 network input, 6.5 MB per
+  // 640x640 frame, is never written or read); the bilinear mode keeps K3 as its own pass
+  FusedInput fi{d_bgr, p.src_h, p.src_w, p.new_h, p.new_w, p.top, p.left, p.mode};
+  const Op& op0 = y->ops.front();
+  static const bool no_fuse = getenv("EIOKU_STEM_FUSE") && atoi(getenv("EIOKU_STEM_FUSE")) == 0;
+  const bool fuse = !no_fuse && op0.kind == kConv && op0.in_buf == y->in_buf && op0.res_buf < 0 && op0.f32_out < 0 &&
+                    fused_input_ok(y->weights[op0.conv], fi, Slice{}, nullptr);
+  if (!fuse) {
+    rc = letterbox_forward(d_bgr, n, p, y->bufs[y->in_buf].ptr, stream);
+    if (rc) return rc;
+  }
+  rc = run_network(y, n, p.out_h, p.out_w, stream, fuse ? &fi : nullptr);
   if (rc) return rc;
 
   int Hl[3], Wl[3], A = 0;

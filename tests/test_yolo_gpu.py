@@ -218,6 +218,26 @@ def test_detect_end_to_end_vs_oracle(gpu):
     det.close()
 
 
+@pytest.mark.parametrize("h,w", [(470, 640), (940, 1280), (360, 500), (96, 160)])
+def test_fused_stem_equals_letterbox_then_network(gpu, h, w):
+    """detect() lets the stem read the BGR frames itself in the copy / exact-half letterbox modes (the fp16
+    network input is never materialised); K3 -> eioku_yolo_forward -> K6/K7 is the unfused route.  Same
+    arithmetic, so the detections must be the same BYTES (114 padding rows, image borders and the bilinear
+    mode, which stays unfused, included)."""
+    frames = _dev(prng.synth_frames_bgr(33, 3, h, w), gpu)
+    det = D.Yolov8Detector("n", 80, W.random_state("n", 80, seed=3))
+    det.calibrate_random_head(frames, frac=0.02)
+    dets, counts = det.detect(frames, conf=0.25)
+    x, plan = D.letterbox_f16(frames)
+    box, cls = det.forward_raw(x)
+    dets2, counts2 = D.postprocess(box, cls, plan, 0.25, 0.7, 300)
+    assert counts.sum() > 0
+    assert np.array_equal(counts, counts2)
+    for i in range(len(counts)):
+        assert np.array_equal(dets[i, :counts[i]], dets2[i, :counts[i]])
+    det.close()
+
+
 def test_detect_empty_batch_and_missing_weights(gpu):
     import torch
     from eioku_amd._lib import EiokuHipError
