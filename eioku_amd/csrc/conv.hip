@@ -53,6 +53,7 @@ __device__ __forceinline__ int fast_div(int x, int d, float rd) {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_f32(float v) {
@@ -674,6 +675,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
   constexpr int R = (NPIX + 255) / 256;
   constexpr int ROWS = 16 * NF;
   constexpr int NB = SRC == 0 ? 1 : (SRC == 1 ? 3 : 12);  // raw registers per slot
+  // SRC 3 (copy mode, frame rows / padding 4-pixel aligned): a slot is a GROUP of 4 pixels = 12 bytes = one
+  // aligned dwordx3 load; the staged columns start 3 pixels left of the patch (x = 32*tw - 4) so that groups
+  // never straddle the image edge.  153 groups per tile: one per thread.
+  constexpr int GPR = (PW + 3 + 3) / 4;  // groups per patch row
+  static_assert(SRC != 3 || (PH * GPR <= 256 && S == 2), "one group per thread");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wt = reinterpret_cast<uint4*>(smem);  // [3 k-steps][ROWS][4 taps] swizzled per row
@@ -691,6 +697,17 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
       *reinterpret_cast<u32x4*>(wt + (idx & ~3) + (q ^ ((row >> 1) & 3))) = v;
     }
   }
+  int g_off[4] = {0, 0, 0, 0};
+  const int g_py = tid / GPR, g_x = (tid - g_py * GPR) * 4 - 3;  // first pixel of the group, patch coordinates
+  if (SRC == 3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = g_x + i;
+      const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
+      g_off[i] = (tid < PH * GPR && px >= 0 && px < PW) ? g_py * PWS + col : PATCH_U - 1;
+    }
+  }
+  u32x3 graw = u32x3{0, 0, 0};
   int s_off[R], s_py[R], s_px[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -715,6 +732,16 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
     const int ih0 = nx_th * kTH * S - PAD, iw0 = nx_tw * kTW * S - PAD;
     s_in = 0;
     s_img = 0;
+    if (SRC == 3) {
+      const int ih = ih0 + g_py, iw = iw0 + g_x;  // iw is a multiple of 4; so are W, left and new_w
+      const bool in = tid < PH * GPR && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      const int y = ih - fs.top, x = iw - fs.left;
+      const bool img = in && (unsigned)y < (unsigned)fs.new_h && (unsigned)x < (unsigned)fs.new_w;
+      s_in = in;
+      s_img = img;
+      graw = *reinterpret_cast<const u32x3*>(fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + y) * fs.src_w + x) * 3 : 0));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const int ih = ih0 + s_py[j], iw = iw0 + s_px[j];
@@ -753,8 +780,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
         for (int c = 0; c < 3; ++c)
           v[c] = SRC == 1 ? (int)raw[j][c] : (int)((raw[j][c] + raw[j][c + 3] + raw[j][6 + c] + raw[j][9 + c] + 2) >> 2);
       }
-      // BGR -> RGB, /255 in fp32, fp16 RNE: exactly K3's arithmetic
-      f16x4 lo = f16x4{(_Float16)((float)v[2] / 255.0f), (_Float16)((float)v[1] / 255.0f), (_Float16)((float)v[0] / 255.0f),
+      // BGR -> RGB, /255, fp16 RNE: K3's values
+      constexpr float k255 = 1.0f / 255.0f;  // == division after the fp16 rounding, see SRC 3 below
+      f16x4 lo = f16x4{(_Float16)((float)v[2] * k255), (_Float16)((float)v[1] * k255), (_Float16)((float)v[0] * k255),
                        (_Float16)0.f};
       u32x2 l2 = __builtin_bit_cast(u32x2, lo);
       u32x4 u = u32x4{l2[0], l2[1], 0, 0};
@@ -786,8 +814,27 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
   int buf = 0;
   for (; tile < total_tiles; tile += gridDim.x) {
     uint4* pb = patch + buf * PATCH_U;
+    if (SRC == 3) {
 #pragma unroll
-    for (int j = 0; j < R; ++j) *reinterpret_cast<u32x4*>(pb + s_off[j]) = unit_of(j);
+      for (int i = 0; i < 4; ++i) {
+        // pixel i of the group = bytes 3i..3i+2 (B, G, R) of the 12 loaded ones
+        // fp16(v * (1/255)) == fp16(v / 255) for all 256 byte values (tests/test_oracle_yolo.py checks the
+        // identity exhaustively), so the fused path spares the 12 IEEE divisions per group
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int byte = 3 * i + c;
+          v[c] = s_img ? (float)((graw[byte >> 2] >> (8 * (byte & 3))) & 0xffu) : 114.0f;
+        }
+        constexpr float k255 = 1.0f / 255.0f;
+        f16x4 lo = f16x4{(_Float16)(v[2] * k255), (_Float16)(v[1] * k255), (_Float16)(v[0] * k255), (_Float16)0.f};
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo);
+        *reinterpret_cast<u32x4*>(pb + g_off[i]) = s_in ? u32x4{l2[0], l2[1], 0, 0} : u32x4{0, 0, 0, 0};
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < R; ++j) *reinterpret_cast<u32x4*>(pb + s_off[j]) = unit_of(j);
+    }
     __syncthreads();  // double-buffered patch: one barrier per tile (also orders the weight copy before tile 0)
     const int tn = nx_n, tth = nx_th, ttw = nx_tw;
     const int next = tile + gridDim.x;
@@ -850,6 +897,7 @@ int launch_c8_dispatch(int nf, int src, const ConvArgs& a, const FusedSrc& fs, i
   if (nf == NF_) {                                                                \
     if (src == 0) return launch_c8<NF_, S, 0>(a, fs, ntiles, stream);              \
     if (src == 1) return launch_c8<NF_, S, 1>(a, fs, ntiles, stream);              \
+    if (src == 3) return launch_c8<NF_, S, 3>(a, fs, ntiles, stream);              \
     return launch_c8<NF_, S, 2>(a, fs, ntiles, stream);                            \
   }
   EIOKU_C8(1) EIOKU_C8(2) EIOKU_C8(3) EIOKU_C8(4) EIOKU_C8(5)
@@ -1158,6 +1206,10 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
     if (fused) {
       fs = FusedSrc{fused->bgr, fused->src_h, fused->src_w, fused->new_h, fused->new_w, fused->top, fused->left};
       src = fused->mode == 0 ? 1 : 2;
+      // copy mode with 4-pixel aligned rows and padding: 12-byte group loads instead of byte loads
+      if (src == 1 && fused->src_w % 4 == 0 && fused->left % 4 == 0 && fused->new_w % 4 == 0 && W % 4 == 0 &&
+          ((uintptr_t)fused->bgr & 3) == 0)
+        src = 3;
     }
     rc = launch_c8_dispatch<2>(cw.nf, src, a, fs, cw.ntiles, stream, &handled);
   }

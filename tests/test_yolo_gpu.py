@@ -218,7 +218,7 @@ def test_detect_end_to_end_vs_oracle(gpu):
     det.close()
 
 
-@pytest.mark.parametrize("h,w", [(470, 640), (940, 1280), (360, 500), (96, 160)])
+@pytest.mark.parametrize("h,w", [(470, 640), (640, 470), (640, 472), (940, 1280), (1280, 940), (96, 160)])
 def test_fused_stem_equals_letterbox_then_network(gpu, h, w):
     """detect() lets the stem read the BGR frames itself in the copy / exact-half letterbox modes (the fp16
     network input is never materialised); K3 -> eioku_yolo_forward -> K6/K7 is the unfused route.  Same
