@@ -50,7 +50,10 @@ def parse_args():
     ap.add_argument("--knn-nq", type=int, default=1024)
     ap.add_argument("--knn-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prof-every", type=int, default=4, help="HIP-event kernel timing on every n-th timed step (0: off)")
+    ap.add_argument("--depth", type=int, default=2, help="detector handles alternating over consecutive steps (with --overlap)")
+    ap.add_argument("--overlap", type=int, default=1, help="1: scene / detect / embed on three HIP streams; 0: one stream")
+    ap.add_argument("--prof-every", type=int, default=-1,
+                    help="HIP-event kernel timing on every n-th timed step (0: off, -1: one step in the middle of the region)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU oracle sample budget")
     return ap.parse_args()
 
@@ -82,26 +85,56 @@ class Pipeline:
             self.det = detect.Yolov8Detector.from_model_name(args.model, seed=7)  # random-init weights, exact shapes
             # a random net's logit scale is arbitrary: give it a trained detector's candidate density
             self.det.calibrate_random_head(self.frames[0][:8], frac=0.01, conf=args.conf)
+            # --depth 2: a second detector handle (same weights, its own activation buffers) on its own stream, so
+            # that consecutive batches overlap -- two workers per GPU, as the reference's deployment scales
+            self.dets = [self.det]
+            for _ in range(1, max(1, args.depth if args.overlap else 1)):
+                d2 = detect.Yolov8Detector.from_model_name(args.model, seed=7)
+                d2.load_state(self.det._state)
+                self.dets.append(d2)
         if "embed" in self.stages:
             self.enc = embed.MiniLMEncoder(embed.random_state(embed.MINILM_L6_V2, 11))
             g = torch.Generator(device="cpu").manual_seed(11 + rank)
             self.ids = torch.randint(1000, 30000, (args.segments, args.seq_len), generator=g, dtype=torch.int32).to(device)
             self.mask = torch.ones((args.segments, args.seq_len), dtype=torch.uint8, device=device)
         self.last = None
+        # The three stages of a step share no data (the reference runs them as separate tasks): each gets its own
+        # HIP stream so that the many small launches of one (20x20 convs, M=1024 GEMMs, each a fraction of the
+        # chip) fill the CUs and the launch-to-launch gaps that another leaves idle.
+        self.streams = None
+        if args.overlap:
+            self.streams = {k: torch.cuda.Stream(device=device) for k in ("scene", "detect", "embed")}
+            for j in range(1, len(getattr(self, "dets", [0]))):
+                self.streams[f"detect{j}"] = torch.cuda.Stream(device=device)
 
-    def step(self, i):
+    def _on(self, name):
+        import contextlib
+
+        import torch
+
+        return torch.cuda.stream(self.streams[name]) if self.streams and not self.serial else contextlib.nullcontext()
+
+    def step(self, i, serial=False):
+        """One batch through scene + detect + embed.  serial=True (the HIP-event profiled steps): everything on
+        the current stream, so that a kernel's event-bracketed duration is its own and not a shared chip's."""
         from eioku_amd import scene
+
+        self.serial = serial
 
         f = self.frames[i & 1]
         out = []
-        if "scene" in self.stages:
-            out.append(scene.hsv_sums(f, self.prev, keep_on_device=True))
-            out.append(scene.luma_sad(self.luma[i & 1], keep_on_device=True))
-            self.prev = f[-1]
         if self.det is not None:
-            out.append(self.det.detect(f, conf=self.args.conf, keep_on_device=True))
+            j = i % len(self.dets) if self.streams else 0
+            with self._on("detect" if j == 0 else f"detect{j}"):
+                out.append(self.dets[j].detect(f, conf=self.args.conf, keep_on_device=True))
         if self.enc is not None:
-            out.append(self.enc.encode_ids(self.ids, self.mask))
+            with self._on("embed"):
+                out.append(self.enc.encode_ids(self.ids, self.mask))
+        if "scene" in self.stages:
+            with self._on("scene"):
+                out.append(scene.hsv_sums(f, self.prev, keep_on_device=True))
+                out.append(scene.luma_sad(self.luma[i & 1], keep_on_device=True))
+                self.prev = f[-1]
         self.last = out
 
     def dominant(self):
@@ -138,6 +171,11 @@ def knn_part(args, device, rank, world):
         dist.barrier()
     torch.cuda.synchronize()
     _lib.prof_enable(True)
+    def profiled(i):
+        if args.prof_every < 0:
+            return i == args.steps // 2
+        return args.prof_every > 0 and i % args.prof_every == 0
+
     _lib.prof_reset()
     t0 = time.perf_counter()
     for _ in range(args.knn_iters):
@@ -248,17 +286,28 @@ def main():
         pipe.step(i)
     barrier()
     # HIP-event hooks bracket every conv launch on the kernel's own stream; they are sampled (every
-    # --prof-every-th step of the timed region) because 2 event records per launch x ~130 launches per step are
-    # themselves ~10% of a step
+    # --prof-every-th step of the timed region, run un-overlapped) because 2 event records per launch x ~130
+    # launches per step are themselves ~15% of a step and because overlapped stages stretch each other's kernels
+    def profiled(i):
+        if args.prof_every < 0:
+            return i == args.steps // 2
+        return args.prof_every > 0 and i % args.prof_every == 0
+
     _lib.prof_reset()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        _lib.prof_enable(args.prof_every > 0 and i % args.prof_every == 0)
-        pipe.step(i)
+        if profiled(i):
+            torch.cuda.synchronize()  # drain the overlapped steps, time this one's kernels alone, drain again
+            _lib.prof_enable(True)
+            pipe.step(i, serial=True)
+            torch.cuda.synchronize()
+            _lib.prof_enable(False)
+        else:
+            pipe.step(i)
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.prof_enable(False)
-    pipe.prof_steps = sum(1 for i in range(args.steps) if args.prof_every > 0 and i % args.prof_every == 0)
+    pipe.prof_steps = sum(1 for i in range(args.steps) if profiled(i))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -24,6 +24,7 @@ void* scratch(ScratchSlot slot, size_t bytes);  // nullptr + error set on failur
 // hipEvent brackets around tagged kernel launches (no-ops unless eioku_prof_enable(1)).
 void prof_start(int tag, hipStream_t stream);
 void prof_stop(int tag, hipStream_t stream);
+bool prof_enabled();
 
 }  // namespace eioku
 

@@ -1091,7 +1091,8 @@ int pick_nf(int cout, int ks, int nchunks, int stride) {
     // two workgroups per CU with a single-buffered patch; otherwise fall through to the generic rule
     for (int nf : {4, 3, 2, 1}) {
       const int waste = ((frags + nf - 1) / nf) * nf - frags;
-      if (waste <= (frags >= 4 ? 1 : 0) && persist_lds(nf, stride, nchunks, false) <= 75 * 1024) {
+      static const int lim_kb = getenv("EIOKU_PERSIST_KB") ? atoi(getenv("EIOKU_PERSIST_KB")) : 75;
+      if (waste <= (frags >= 4 ? 1 : 0) && persist_lds(nf, stride, nchunks, false) <= (size_t)lim_kb * 1024) {
         // a 1-fragment tile re-reads the halo patch once per 16 couts and is LDS-read bound (3 reads per 2
         // MFMAs): with >= 5 fragments take 3 per tile even if only one workgroup then fits per CU
         if (nf == 1 && frags >= 5 && persist_lds(3, stride, nchunks, false) <= 150 * 1024) return 3;

@@ -38,6 +38,8 @@ void prof_stop(int tag, hipStream_t stream) {
   g_prof_used[tag]++;
 }
 
+bool prof_enabled() { return g_prof; }
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
