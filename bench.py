@@ -80,18 +80,15 @@ class Pipeline:
         self.luma = [f[..., 1].contiguous() for f in self.frames]  # stands in for the decoder's Y plane
         self.prev = None
         self.det = None
+        self.pdet = None
         self.enc = None
         if "detect" in self.stages:
             self.det = detect.Yolov8Detector.from_model_name(args.model, seed=7)  # random-init weights, exact shapes
             # a random net's logit scale is arbitrary: give it a trained detector's candidate density
             self.det.calibrate_random_head(self.frames[0][:8], frac=0.01, conf=args.conf)
-            # --depth 2: a second detector handle (same weights, its own activation buffers) on its own stream, so
-            # that consecutive batches overlap -- two workers per GPU, as the reference's deployment scales
-            self.dets = [self.det]
-            for _ in range(1, max(1, args.depth if args.overlap else 1)):
-                d2 = detect.Yolov8Detector.from_model_name(args.model, seed=7)
-                d2.load_state(self.det._state)
-                self.dets.append(d2)
+            # --depth 2: eioku_amd.detect.PipelinedDetector, the same object ModelManager's frame loop runs on: a
+            # second handle (same weights, own activation buffers) on its own stream, consecutive batches overlap
+            self.pdet = detect.PipelinedDetector(self.det, depth=max(1, args.depth), device=device) if args.overlap else None
         if "embed" in self.stages:
             self.enc = embed.MiniLMEncoder(embed.random_state(embed.MINILM_L6_V2, 11))
             g = torch.Generator(device="cpu").manual_seed(11 + rank)
@@ -103,9 +100,7 @@ class Pipeline:
         # chip) fill the CUs and the launch-to-launch gaps that another leaves idle.
         self.streams = None
         if args.overlap:
-            self.streams = {k: torch.cuda.Stream(device=device) for k in ("scene", "detect", "embed")}
-            for j in range(1, len(getattr(self, "dets", [0]))):
-                self.streams[f"detect{j}"] = torch.cuda.Stream(device=device)
+            self.streams = {k: torch.cuda.Stream(device=device) for k in ("scene", "embed")}
 
     def _on(self, name):
         import contextlib
@@ -124,9 +119,12 @@ class Pipeline:
         f = self.frames[i & 1]
         out = []
         if self.det is not None:
-            j = i % len(self.dets) if self.streams else 0
-            with self._on("detect" if j == 0 else f"detect{j}"):
-                out.append(self.dets[j].detect(f, conf=self.args.conf, keep_on_device=True))
+            if self.pdet is not None and not serial:
+                self.pdet.submit(f, conf=self.args.conf)
+                if self.pdet.in_flight() >= self.pdet.depth:
+                    out.append(self.pdet.result_on_device())  # results stay in HBM; nothing waits on the host
+            else:
+                out.append(self.det.detect(f, conf=self.args.conf, keep_on_device=True))
         if self.enc is not None:
             with self._on("embed"):
                 out.append(self.enc.encode_ids(self.ids, self.mask))

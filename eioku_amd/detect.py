@@ -244,6 +244,74 @@ class Yolov8Detector:
         return dets, counts
 
 
+class PipelinedDetector:
+    """``depth`` detector handles with the same weights, each on its own HIP stream: ``submit`` enqueues a batch
+    and returns at once, ``result`` hands back ``(dets, counts)`` in submission order.  Consecutive batches then
+    overlap on the GPU (the network's many small launches leave a single stream a quarter idle) and the upload of
+    batch i+1 overlaps the kernels of batch i; the frame loop of ``ModelManager`` and ``bench.py`` both run on it.
+    """
+
+    def __init__(self, first: Yolov8Detector, depth: int = 2, device=None):
+        import torch
+
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.names = first.names
+        self._handles = [first]
+        for _ in range(1, depth):
+            d = Yolov8Detector(first.variant, first.nc, None, first.names)
+            d.load_state(first._state)
+            self._handles.append(d)
+        self._device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._streams = [torch.cuda.Stream(device=self._device) for _ in self._handles]
+        self._pending = []  # (dets, counts, event, frames kept alive)
+        self._n = 0
+
+    @property
+    def depth(self) -> int:
+        return len(self._handles)
+
+    def in_flight(self) -> int:
+        return len(self._pending)
+
+    def submit(self, frames_bgr, conf: float = 0.25, iou: float = 0.7, max_det: int = 300, imgsz: int = 640) -> None:
+        import torch
+
+        j = self._n % len(self._handles)
+        self._n += 1
+        s = self._streams[j]
+        if on_device(frames_bgr):
+            s.wait_stream(torch.cuda.current_stream(self._device))  # the caller produced the frames on its stream
+        with torch.cuda.stream(s):
+            f = frames_bgr if on_device(frames_bgr) else torch.from_numpy(np.ascontiguousarray(frames_bgr)).to(
+                self._device, non_blocking=True)
+            dets, counts = self._handles[j].detect(f, conf=conf, iou=iou, max_det=max_det, imgsz=imgsz, keep_on_device=True)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        self._pending.append((dets, counts, ev, f))
+
+    def result(self):
+        """Oldest submitted batch: ``(dets structured (n,max_det), counts int32 (n,))`` on the host."""
+        dets, counts, ev, _ = self._pending.pop(0)
+        ev.synchronize()
+        n, max_det = int(dets.shape[0]), int(dets.shape[1])
+        return dets.cpu().numpy().view(DET_DTYPE).reshape(n, max_det), counts.cpu().numpy()
+
+    def result_on_device(self):
+        """Oldest submitted batch as the raw CUDA tensors plus the event that marks them complete."""
+        dets, counts, ev, _ = self._pending.pop(0)
+        return dets, counts, ev
+
+    def close(self):
+        import torch
+
+        if self._pending:
+            torch.cuda.synchronize(self._device)
+            self._pending.clear()
+        for h in self._handles:
+            h.close()
+
+
 def letterbox_f16(frames_bgr, imgsz: int = 640):
     """K3 alone: CUDA uint8 (n,h,w,3) -> CUDA fp16 (n,out_h,out_w,8) network input (RGB/255 + 5 zero channels)."""
     import torch

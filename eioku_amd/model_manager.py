@@ -140,12 +140,15 @@ class ModelManager:
         pend_frames: list[np.ndarray] = []
         pend_meta: list[tuple[int, int]] = []
 
-        def flush():
-            if not pend_frames:
-                return
-            batch = np.stack(pend_frames)
-            dets, counts = detector.detect(batch, conf=confidence_threshold)
-            for (frame_idx, timestamp_ms), row, cnt in zip(pend_meta, dets, counts):
+        # Two batches in flight on the HIP path (PipelinedDetector: second handle + stream); results are consumed
+        # in submission order, so the detection list is the one the synchronous loop produces.
+        from .detect import PipelinedDetector, Yolov8Detector
+
+        pipe = PipelinedDetector(detector, depth=2) if isinstance(detector, Yolov8Detector) else None
+        metas: list[list[tuple[int, int]]] = []
+
+        def emit(meta, dets, counts):
+            for (frame_idx, timestamp_ms), row, cnt in zip(meta, dets, counts):
                 for d in row[: int(cnt)]:
                     x1, y1, x2, y2 = (np.float32(d[k]) for k in ("x1", "y1", "x2", "y2"))
                     confidence = float(np.float32(d["conf"]))  # float32 -> Python float, as float(tensor)
@@ -162,6 +165,21 @@ class ModelManager:
                     if face:
                         det["cluster_id"] = None
                     detections.append(det)
+
+        def drain(keep: int):
+            while pipe is not None and pipe.in_flight() > keep:
+                emit(metas.pop(0), *pipe.result())
+
+        def flush():
+            if not pend_frames:
+                return
+            batch = np.stack(pend_frames)
+            if pipe is None:
+                emit(list(pend_meta), *detector.detect(batch, conf=confidence_threshold))
+            else:
+                pipe.submit(batch, conf=confidence_threshold)
+                metas.append(list(pend_meta))
+                drain(pipe.depth - 1)
             pend_frames.clear()
             pend_meta.clear()
 
@@ -181,9 +199,10 @@ class ModelManager:
                         break
                 frame_idx += 1
             flush()
+            drain(0)
         finally:
             cap.release()
-            close = getattr(detector, "close", None)
+            close = pipe.close if pipe is not None else getattr(detector, "close", None)
             if close:
                 close()
         return detections
