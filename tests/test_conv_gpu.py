@@ -58,6 +58,11 @@ CASES = [
     (2, 21, 19, 136, 64, 3, 2),   # odd sizes, cin not a multiple of 32
     (5, 5, 7, 128, 32, 3, 1),     # several frames inside one 128-pixel tile
     (3, 7, 5, 160, 48, 3, 2),
+    # deep-K 1x1 on few pixels, cin tail
+    (2, 20, 20, 512, 256, 1, 1),
+    (1, 10, 10, 256, 128, 1, 1),
+    (1, 9, 7, 136, 80, 1, 1),
+    (2, 5, 3, 160, 64, 1, 1),
 ]
 
 
