@@ -12,6 +12,7 @@ OpenCV compute in Python-float / C-float arithmetic on the host, in the same ord
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 from dataclasses import dataclass
 
@@ -76,8 +77,12 @@ def _linear_coeffs(src: int, dst: int, clamp_edges: bool):
     return ofs, coef
 
 
+@functools.lru_cache(maxsize=64)
 def letterbox_plan(h: int, w: int, imgsz: int = 640, stride: int = 32, auto: bool = True) -> LetterboxPlan:
-    """Ultralytics ``LetterBox(new_shape=imgsz, auto=True, stride=32)`` + ``scale_boxes`` geometry."""
+    """Ultralytics ``LetterBox(new_shape=imgsz, auto=True, stride=32)`` + ``scale_boxes`` geometry.
+
+    Cached per frame size (the tap tables are a Python loop over every destination row and column); treat the
+    returned plan and its arrays as read-only."""
     r = min(imgsz / h, imgsz / w)
     new_w, new_h = int(round(w * r)), int(round(h * r))
     dw, dh = imgsz - new_w, imgsz - new_h
