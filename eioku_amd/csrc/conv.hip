@@ -1220,6 +1220,13 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
     rc = EIOKU_EINVAL;
     handled = true;
   }
+  // maps too small for 8x16 tiles (20x20: 52 % of a tiling is outside the map): flattened-pixel tiles whatever
+  // the depth.  Measured: 80->80 @20 19.8 -> 13.8 us, 64->64 @20 13.2 -> 10.5; at 40x40 resident weights still
+  // win (64->64 20.7 vs 25.8 us), hence the 24-pixel cut.
+  static const int flat_wo = getenv("EIOKU_FLAT_WO") ? atoi(getenv("EIOKU_FLAT_WO")) : 24;
+  if (!handled && cw.ks == 3 && cw.nchunks >= 2 && cw.nchunks <= 3 && a.Wo <= flat_wo)
+    rc = cw.stride == 1 ? launch_flat_dispatch<1>(cw.nf, a, cw.ntiles, stream, &handled)
+                        : launch_flat_dispatch<2>(cw.nf, a, cw.ntiles, stream, &handled);
   if (!handled && cw.ks == 3 && cw.nchunks <= 3) {
     // double-buffer the patch only when that still leaves two workgroups per CU
     const bool db = persist_lds(cw.nf, cw.stride, cw.nchunks, true) <= 75 * 1024;

@@ -13,6 +13,7 @@ SHAPES = [  # name, cin, cout, k, s, hw(in)
     ("cv2.1.0", 128, 64, 3, 1, 40), ("cv3.1.0", 128, 80, 3, 1, 40), ("cv2.2.0", 256, 64, 3, 1, 20),
     ("cv3.2.0", 256, 80, 3, 1, 20), ("m6.m", 64, 64, 3, 1, 40), ("cv3.2.1", 80, 80, 3, 1, 20),
     ("m6.cv2", 256, 128, 1, 1, 40), ("m15.cv1", 192, 64, 1, 1, 80), ("m2.cv1", 32, 32, 1, 1, 160), ("m8.cv1", 256, 256, 1, 1, 20),
+    ("cv3.1.1", 80, 80, 3, 1, 40), ("cv2.2.1", 64, 64, 3, 1, 20),
     ("m12.cv1", 384, 128, 1, 1, 40), ("m9.cv2", 512, 256, 1, 1, 20), ("m21.cv1", 384, 256, 1, 1, 20),
     ("cv2.0.0", 64, 64, 3, 1, 80), ("cv3.0.0", 64, 80, 3, 1, 80), ("cv3.0.1", 80, 80, 3, 1, 80), ("2.m", 16, 16, 3, 1, 160),
     ("4.m", 32, 32, 3, 1, 80), ("model.3", 32, 64, 3, 2, 160), ("model.16", 64, 64, 3, 2, 80),
