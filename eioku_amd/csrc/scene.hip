@@ -188,9 +188,11 @@ __device__ __forceinline__ void hsv_px(int b, int g, int r, const int* __restric
   int vmin = min(min(b, g), r);
   int diff = v - vmin;
   int s = (__mul24(diff, sdiv[v]) + 2048) >> 12;
-  int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+  // masks, as in OpenCV's own source: ternaries here were compiled to a divergent branch per pixel
+  const int vr = -(int)(v == r), vg = -(int)(v == g);
+  int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + (~vg & (r - g + 4 * diff))));
   h = (__mul24(h, hdiv[diff]) + 2048) >> 12;  // arithmetic shift: floor, as in the C source
-  h += (h < 0) ? 180 : 0;
+  h += (h >> 31) & 180;
   H = h;
   S = s;
   V = v;
@@ -291,9 +293,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_hsv_sums(const uint8_t* __restric
       const int t = t0 + k;
       if (t < t_end) {
         Quad3 nxt[Q];
-        const bool more = t + 1 < t_end;  // wave-uniform
-        if (more) {
-          const uint8_t* f = frames + (size_t)(t + 1) * frame_stride;
+        {
+          // unconditional (the last frame is re-read once): behind a branch the compiler cannot count the load
+          // and waits for it with vmcnt(0) BEFORE converting the current frame
+          const int tn = t + 1 < t_end ? t + 1 : t_end - 1;
+          const uint8_t* f = frames + (size_t)tn * frame_stride;
 #pragma unroll
           for (int u = 0; u < Q; ++u) nxt[u] = load_quad<ALIGNED>(f, q[u]);
         }
@@ -314,10 +318,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_hsv_sums(const uint8_t* __restric
           pV[u] = V;
         }
         have_prev = true;
-        if (more) {
 #pragma unroll
-          for (int u = 0; u < Q; ++u) cur[u] = nxt[u];
-        }
+        for (int u = 0; u < Q; ++u) cur[u] = nxt[u];
       }
     }
     flush_sums<kG, 3>(acc, s_red, t0, t_end, sums);
