@@ -99,3 +99,22 @@ def test_batch_512x128_properties(gpu):
     want = obert.encode(state, cfg, ids[[3, 200]], mask[[3, 200]])
     assert _close(out[[3, 200]], want)
     enc.close()
+
+
+def test_full_size_batch_invariance(gpu):
+    """BASELINE cfg3 size (512 x 128): a segment's embedding does not depend on its batch.  Bit-exact for
+    batches that take the same GEMM configuration (tile size and split-K are chosen from the token count),
+    within the parity tolerance across configurations."""
+    cfg = dict(embed.MINILM_L6_V2, vocab=3000)
+    enc = embed.MiniLMEncoder(embed.random_state(cfg, 5), cfg)
+    ids, mask = _inputs(3000, 512, 128, 9)
+    full = enc.encode_ids(ids, mask)
+    assert np.isfinite(full).all() and np.allclose(np.linalg.norm(full, axis=1), 1.0, atol=1e-5)
+    a = enc.encode_ids(ids[:256], mask[:256])
+    b = enc.encode_ids(ids[256:], mask[256:])
+    assert np.array_equal(np.concatenate([a, b]), full)      # 32768 / 65536 tokens: same kernels, same order
+    small = enc.encode_ids(ids[:8], mask[:8])                 # 1024 tokens: 64x64 tiles + split-K planes
+    assert _close(small, full[:8])
+    again = enc.encode_ids(ids[:8], mask[:8])
+    assert np.array_equal(small, again)                       # split-K planes are summed in plane order
+    enc.close()

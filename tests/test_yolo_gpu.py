@@ -238,6 +238,37 @@ def test_fused_stem_equals_letterbox_then_network(gpu, h, w):
     det.close()
 
 
+def test_full_size_batch_split_invariance_and_pipelined_order(gpu):
+    """BASELINE cfg2 size (64 x 640 x 640), size-independent properties: a frame's detections do not depend on
+    which frames share its batch (the flattened-pixel kernels cut tiles ACROSS frame borders, the persistent ones
+    walk tiles grid-stride over the whole batch), and PipelinedDetector (two handles, two streams) returns, in
+    submission order, exactly what the synchronous detector returns -- for device and host inputs."""
+    import torch
+
+    frames = _dev(prng.synth_frames_bgr(77, 64, 640, 640), gpu)
+    det = D.Yolov8Detector("n", 80, W.random_state("n", 80, seed=5))
+    det.calibrate_random_head(frames[:8], frac=0.01)
+    dets, counts = det.detect(frames, conf=0.25)
+    assert counts.sum() > 64
+    for lo, hi in [(0, 1), (1, 24), (24, 64)]:
+        d2, c2 = det.detect(frames[lo:hi].contiguous(), conf=0.25)
+        assert np.array_equal(c2, counts[lo:hi])
+        for i in range(hi - lo):
+            assert np.array_equal(d2[i, :c2[i]], dets[lo + i, :counts[lo + i]])
+    pipe = D.PipelinedDetector(det, depth=2)
+    chunks = [(0, 16), (16, 48), (48, 64), (0, 64)]
+    for k, (lo, hi) in enumerate(chunks):
+        batch = frames[lo:hi].contiguous()
+        pipe.submit(batch.cpu().numpy() if k % 2 else batch, conf=0.25)
+    for lo, hi in chunks:
+        d2, c2 = pipe.result()
+        assert np.array_equal(c2, counts[lo:hi])
+        for i in range(hi - lo):
+            assert np.array_equal(d2[i, :c2[i]], dets[lo + i, :counts[lo + i]])
+    assert pipe.in_flight() == 0
+    pipe.close()
+
+
 def test_detect_empty_batch_and_missing_weights(gpu):
     import torch
     from eioku_amd._lib import EiokuHipError
