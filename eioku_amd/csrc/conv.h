@@ -51,8 +51,12 @@ struct FusedInput {
   int mode;             // LetterboxPlan::mode, 0 or 2
 };
 bool fused_input_ok(const ConvWeights& cw, const FusedInput& f, Slice res, const float* out_f32);
+// `post` (3x3 persistent kernel only, see conv_post_ok): a following 1x1 convolution applied to the tile while it
+// is still on chip; `out` then receives post's output and cw's own output tensor is never written.
+bool conv_post_ok(const ConvWeights& cw, const ConvWeights& post);
 int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out, float* out_f32,
-                 Slice res, int act, hipStream_t stream, const FusedInput* fused = nullptr);
+                 Slice res, int act, hipStream_t stream, const FusedInput* fused = nullptr,
+                 const ConvWeights* post = nullptr, int post_act = kActSiLU);
 
 inline int conv_out_dim(int x, int ks, int stride) { return (x + 2 * (ks / 2) - ks) / stride + 1; }
 

@@ -39,6 +39,11 @@ struct ConvArgs {
   int Ho, Wo, Cout, out_cs;
   int res_cs;
   int tiles_w, tiles_h, nchunks, act;
+  // fused following 1x1 (persistent kernel, POST): out2 = act2(W2 . act(conv3x3) + b2); `out` is then unused
+  const uint4* post_w;
+  const float* post_bias;
+  __half* post_out;
+  int post_out_cs, post_cout, post_act;
 };
 
 // x / d for 0 <= x < 2^24 (exact int->float) with a precomputed 1.0f/d: one multiply and a +-1 fix-up instead
@@ -65,6 +70,16 @@ __device__ __forceinline__ float silu_f32(float v) {
 // `b` = bias of c0..c0+3 and `rpre` = residual of (opix, c0..c0+3) are passed in registers when the
 // caller preloaded them (persistent kernels: a global load inside the tile loop would drain the
 // in-order vmcnt queue and with it the next tile's prefetch); have_rpre = false loads it here.
+// bias + activation only (the fused 3x3+1x1 path keeps the activated tile on chip)
+__device__ __forceinline__ float4v activate_frag(const ConvArgs& a, const float4v& acc, float4 b) {
+  float4v v = acc + float4v{b.x, b.y, b.z, b.w};
+  if (a.act == kActSiLU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = silu_f32(v[j]);
+  }
+  return v;
+}
+
 __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc, size_t opix, int c0, float4 b,
                                            bool have_rpre = false, u32x2 rpre = u32x2{0, 0}) {
   // native vector types throughout: arrays of the HIP uint2/uint4/__half structs end up in scratch memory
@@ -492,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_flat(ConvArgs a, int npix, i
 // output tiles grid-stride, and the NEXT tile's halo patch is already in flight (registers) while the
 // current one is multiplied: one barrier per tile, HBM latency hidden behind the MFMAs.
 // ---------------------------------------------------------------------------------------------
-template <int NF, int S, int NCH, bool DB>
+template <int NF, int S, int NCH, bool DB, bool POST = false>
 __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_tiles) {
   constexpr int KS = 3, TAPS = 9, PAD = 1;
   constexpr int PH = (kTH - 1) * S + KS;
@@ -508,6 +523,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wt = reinterpret_cast<uint4*>(smem);                 // [NCH][WT_U]
   uint4* patch = wt + NCH * WT_U;                             // [DB ? 2 : 1][NCH][PATCH_U] (+ 1 spare unit)
+  // POST: the 1x1 that consumes this conv's output runs here, on the tile still in registers (the intermediate
+  // tensor is never written): its weights [NCH2][16*NF][4 units] and a per-wave [32 px][2*NF units] staging tile
+  constexpr int U1 = 2 * NF;          // 16-byte units per pixel of the intermediate (16*NF channels)
+  constexpr int NCH2 = (NF + 1) / 2;  // 32-channel chunks of the 1x1's K axis
+  static_assert(!POST || NF % 2 == 0, "fused 1x1 needs a multiple of 32 intermediate channels");
+  uint4* wt2 = patch + (DB ? 2 : 1) * NCH * PATCH_U + 1;     // [NCH2][16*NF][4]
+  uint4* tbuf = wt2 + NCH2 * 16 * NF * 4;                     // [4 waves][32][U1]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co_tile = blockIdx.y;
@@ -594,6 +616,16 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
       }
     }
   }
+  float4 biasr2[NF];
+  const uint4* wt2_lane = wt2 + (lane & 15) * 4 + ((lane >> 4) ^ ((lane >> 1) & 3));
+  if (POST) {
+    for (int idx = tid; idx < NCH2 * 16 * NF * 4; idx += 256) {
+      const int row = (idx >> 2) % (16 * NF), unit = idx & 3;
+      *reinterpret_cast<u32x4*>(wt2 + (idx & ~3) + (unit ^ ((row >> 1) & 3))) = *reinterpret_cast<const u32x4*>(a.post_w + idx);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) biasr2[f] = *reinterpret_cast<const float4*>(a.post_bias + f * 16 + (lane >> 4) * 4);
+  }
   int buf = 0;
   for (; tile < total_tiles; tile += gridDim.x) {
     uint4* pb = patch + (DB ? buf : 0) * (NCH * PATCH_U);
@@ -636,14 +668,70 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
 #pragma unroll
     for (int cc = 0; cc < NCH; ++cc) mma_taps<NF, 2>(pb + cc * PATCH_U, wt_lane + cc * WT_U, bpos, acc);
     __builtin_amdgcn_sched_barrier(0);
+    if (POST) {
+      // this wave's 32 pixels x 16*NF activated channels -> its LDS tile in B-operand layout (no other wave reads
+      // it: LDS operations of one wave execute in order, the wave barrier only stops the compiler reordering)
+      uint4* tw = tbuf + wave * 32 * U1;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int oh = tth * kTH + wave * 2 + m;
-      if (oh >= a.Ho || ow >= a.Wo) continue;
-      const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int f = 0; f < NF; ++f)
-        store_frag(a, acc[m][f], opix, co_tile * 16 * NF + f * 16 + (lane >> 4) * 4, biasr[f], res_vec, resv[m][f]);
+        for (int f = 0; f < NF; ++f) {
+          const float4v v = activate_frag(a, acc[m][f], biasr[f]);
+          const f16x4 h = __builtin_convertvector(v, f16x4);
+          const int px = m * 16 + (lane & 15);
+          const int unit = f * 2 + (lane >> 5), half = (lane >> 4) & 1;
+          const int sw = (unit & ~3) | ((unit & 3) ^ ((px >> 1) & 3));
+          *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(tw + px * U1 + sw) + half * 8) = __builtin_bit_cast(u32x2, h);
+        }
+      __builtin_amdgcn_wave_barrier();
+      float4v acc2[2][NF];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc2[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < NCH2; ++kc) {
+        half8 bf[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int px = m * 16 + (lane & 15);
+          uint4 u = tw[px * U1 + kc * 4 + ((lane >> 4) ^ ((px >> 1) & 3))];
+          bf[m] = *reinterpret_cast<half8*>(&u);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          uint4 w = wt2_lane[(kc * NF + f) * 64];
+          const half8 af = *reinterpret_cast<half8*>(&w);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc2[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[m], acc2[m][f], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      ConvArgs a2 = a;
+      a2.out = a.post_out;
+      a2.out_cs = a.post_out_cs;
+      a2.Cout = a.post_cout;
+      a2.act = a.post_act;
+      a2.res = nullptr;
+      a2.out_f32 = nullptr;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int oh = tth * kTH + wave * 2 + m;
+        if (oh >= a.Ho || ow >= a.Wo) continue;
+        const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) store_frag(a2, acc2[m][f], opix, f * 16 + (lane >> 4) * 4, biasr2[f]);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int oh = tth * kTH + wave * 2 + m;
+        if (oh >= a.Ho || ow >= a.Wo) continue;
+        const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+          store_frag(a, acc[m][f], opix, co_tile * 16 * NF + f * 16 + (lane >> 4) * 4, biasr[f], res_vec, resv[m][f]);
+      }
     }
     buf ^= 1;
   }
@@ -906,14 +994,15 @@ int launch_c8_dispatch(int nf, int src, const ConvArgs& a, const FusedSrc& fs, i
   return EIOKU_OK;
 }
 
-template <int NF, int S, int NCH, bool DB>
+template <int NF, int S, int NCH, bool DB, bool POST = false>
 int launch_persist(const ConvArgs& a, int ntiles, hipStream_t stream) {
   constexpr int PH = (kTH - 1) * S + 3, PW = (kTW - 1) * S + 3;
   constexpr int PWS = (S == 2) ? 2 * ((PW + 1) / 2) : PW;
-  constexpr size_t lds = ((size_t)NCH * 9 * 16 * NF * 4 + (DB ? 2 : 1) * (size_t)NCH * PH * PWS * 4 + 1) * 16;
+  constexpr size_t post_units = POST ? (size_t)((NF + 1) / 2) * 16 * NF * 4 + 4 * 32 * 2 * NF : 0;
+  constexpr size_t lds = ((size_t)NCH * 9 * 16 * NF * 4 + (DB ? 2 : 1) * (size_t)NCH * PH * PWS * 4 + 1 + post_units) * 16;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_persist<NF, S, NCH, DB>),
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_persist<NF, S, NCH, DB, POST>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -924,8 +1013,8 @@ int launch_persist(const ConvArgs& a, int ntiles, hipStream_t stream) {
   int bx = num_cus() * per_cu / ntiles;
   if (bx < 1) bx = 1;
   if (bx > total) bx = total;
-  hipLaunchKernelGGL((k_conv3x3_persist<NF, S, NCH, DB>), dim3((unsigned)bx, (unsigned)ntiles), dim3(256), lds, stream,
-                     a, total);
+  hipLaunchKernelGGL((k_conv3x3_persist<NF, S, NCH, DB, POST>), dim3((unsigned)bx, (unsigned)ntiles), dim3(256), lds,
+                     stream, a, total);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }
@@ -947,6 +1036,20 @@ int launch_persist_dispatch(int nf, int nch, bool db, const ConvArgs& a, int nti
   EIOKU_P(1, 2) EIOKU_P(2, 2) EIOKU_P(3, 2) EIOKU_P(4, 2) EIOKU_P(5, 2)
   EIOKU_P(1, 3) EIOKU_P(2, 3) EIOKU_P(3, 3) EIOKU_P(4, 3) EIOKU_P(5, 3)
 #undef EIOKU_P
+  *handled = false;
+  return EIOKU_OK;
+}
+
+// 3x3 + following 1x1 in one launch (the intermediate tensor never exists).  Instantiated for the two shapes the
+// YOLOv8 backbone has (stride-2 conv -> C2f.cv1 with 32 / 64 channels) and their stride-1 twins.
+template <int S>
+int launch_persist_post_dispatch(int nf, int nch, bool db, const ConvArgs& a, hipStream_t stream, bool* handled) {
+  *handled = true;
+#define EIOKU_PP(NF_, NCH_)                                                                             \
+  if (nf == NF_ && nch == NCH_)                                                                          \
+    return db ? launch_persist<NF_, S, NCH_, true, true>(a, 1, stream) : launch_persist<NF_, S, NCH_, false, true>(a, 1, stream);
+  EIOKU_PP(2, 1) EIOKU_PP(4, 1) EIOKU_PP(2, 2) EIOKU_PP(4, 2)
+#undef EIOKU_PP
   *handled = false;
   return EIOKU_OK;
 }
@@ -1161,14 +1264,27 @@ void conv_weights_destroy(ConvWeights* cw) {
   cw->d_b = nullptr;
 }
 
+bool conv_post_ok(const ConvWeights& cw, const ConvWeights& post) {
+  static const bool off = getenv("EIOKU_CONV_POST") && atoi(getenv("EIOKU_CONV_POST")) == 0;
+  if (off) return false;
+  const bool shape = cw.ks == 3 && cw.cin != 8 && cw.nchunks <= 2 && cw.ntiles == 1 && cw.cout == 16 * cw.nf &&
+                     (cw.nf == 2 || cw.nf == 4) && post.ks == 1 && post.cin == cw.cout && post.ntiles == 1 &&
+                     post.nf == cw.nf && post.cout == 16 * post.nf;
+  if (!shape) return false;
+  const size_t extra = ((size_t)((cw.nf + 1) / 2) * 16 * cw.nf * 4 + 4 * 32 * 2 * cw.nf) * 16;
+  return persist_lds(cw.nf, cw.stride, cw.nchunks, false) + extra <= 150 * 1024;
+}
+
 bool fused_input_ok(const ConvWeights& cw, const FusedInput& f, Slice res, const float* out_f32) {
   return cw.ks == 3 && cw.cin == 8 && cw.stride == 2 && cw.nf <= 5 && !res.ptr && !out_f32 && (f.mode == 0 || f.mode == 2) &&
          f.bgr != nullptr;
 }
 
 int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out, float* out_f32,
-                 Slice res, int act, hipStream_t stream, const FusedInput* fused) {
+                 Slice res, int act, hipStream_t stream, const FusedInput* fused, const ConvWeights* post, int post_act) {
   EIOKU_REQUIRE(cw.d_w, "conv weights not created");
+  EIOKU_REQUIRE(!post || (post->d_w && conv_post_ok(cw, *post) && !res.ptr && !out_f32 && !fused && out.ptr),
+                "this pair of layers cannot run as one launch");
   EIOKU_REQUIRE((in.ptr || fused) && (out.ptr || out_f32), "NULL tensor");
   EIOKU_REQUIRE(!fused || fused_input_ok(cw, *fused, res, out_f32), "layer cannot read a fused letterbox input");
   EIOKU_REQUIRE(in.cstride % 8 == 0 && in.coff % 8 == 0, "input slice must be 8-channel aligned");
@@ -1199,6 +1315,12 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
   a.tiles_h = (a.Ho + kTH - 1) / kTH;
   a.nchunks = cw.nchunks;
   a.act = act;
+  a.post_w = post ? reinterpret_cast<const uint4*>(post->d_w) : nullptr;
+  a.post_bias = post ? post->d_b : nullptr;
+  a.post_out = post ? a.out : nullptr;  // `out` is the 1x1's output slice
+  a.post_out_cs = out.cstride;
+  a.post_cout = post ? post->cout : 0;
+  a.post_act = post_act;
   prof_start(EIOKU_PROF_CONV, stream);
   int rc = EIOKU_OK;
   bool handled = false;
@@ -1227,6 +1349,17 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
   if (!handled && cw.ks == 3 && cw.nchunks >= 2 && cw.nchunks <= 3 && a.Wo <= flat_wo)
     rc = cw.stride == 1 ? launch_flat_dispatch<1>(cw.nf, a, cw.ntiles, stream, &handled)
                         : launch_flat_dispatch<2>(cw.nf, a, cw.ntiles, stream, &handled);
+  if (!handled && post) {
+    const size_t extra = ((size_t)((cw.nf + 1) / 2) * 16 * cw.nf * 4 + 4 * 32 * 2 * cw.nf) * 16;
+    const bool db = persist_lds(cw.nf, cw.stride, cw.nchunks, true) + extra <= 75 * 1024;
+    rc = cw.stride == 1 ? launch_persist_post_dispatch<1>(cw.nf, cw.nchunks, db, a, stream, &handled)
+                        : launch_persist_post_dispatch<2>(cw.nf, cw.nchunks, db, a, stream, &handled);
+    if (!handled) {
+      set_error("no fused 3x3+1x1 kernel for nf %d nchunks %d", cw.nf, cw.nchunks);
+      rc = EIOKU_EINVAL;
+      handled = true;
+    }
+  }
   if (!handled && cw.ks == 3 && cw.nchunks <= 3) {
     // double-buffer the patch only when that still leaves two workgroups per CU
     const bool db = persist_lds(cw.nf, cw.stride, cw.nchunks, true) <= 75 * 1024;

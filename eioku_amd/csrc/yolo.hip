@@ -41,6 +41,7 @@ struct Op {
   int res_buf = -1, res_off = 0;
   int act = kActSiLU;
   int f32_out = -1;  // index into head outputs (0..5) or -1
+  bool sole_consumer = false;  // the NEXT op is the only reader of this op's output buffer (set by build_graph)
 };
 
 }  // namespace
@@ -208,6 +209,19 @@ void build_graph(eioku_yolo* y) {
   }
   y->weights.resize(y->names.size());
   y->set.assign(y->names.size(), false);
+  // an op whose whole output buffer is read by the next op and by nothing else may hand its tile over on chip
+  for (size_t i = 0; i + 1 < y->ops.size(); ++i) {
+    Op& op = y->ops[i];
+    if (op.kind != kConv || op.f32_out >= 0 || op.out_buf == y->in_buf) continue;
+    int readers = 0;
+    for (size_t j = 0; j < y->ops.size(); ++j)
+      readers += (y->ops[j].in_buf == op.out_buf) + (y->ops[j].res_buf == op.out_buf);
+    const Op& nx = y->ops[i + 1];
+    int writers = 0;
+    for (const Op& o : y->ops) writers += (o.f32_out < 0 && o.out_buf == op.out_buf);
+    op.sole_consumer = readers == 1 && writers == 1 && nx.in_buf == op.out_buf && nx.res_buf != op.out_buf &&
+                       y->bufs[op.out_buf].ch == y->shapes[op.conv][0];
+  }
 }
 
 int level_dim(int x, int level) {
@@ -268,9 +282,14 @@ int prepare(eioku_yolo* y, int n, int h, int w) {
 int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedInput* fused, double* flops_out,
             int part = 0) {
   double flops = 0;
+  bool skip_next = false;
   for (const Op& op : y->ops) {
     const bool is_first = &op == &y->ops.front();
     if ((part == 1 && !is_first) || (part == 2 && is_first)) continue;
+    if (skip_next) {  // this 1x1 ran inside the previous launch
+      skip_next = false;
+      continue;
+    }
     const Buf& ib = y->bufs[op.in_buf];
     const int H = level_dim(h, ib.level), W = level_dim(w, ib.level);
     Slice in{ib.ptr, ib.ch, op.in_off};
@@ -287,6 +306,22 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
       }
       if (op.res_buf >= 0) res = Slice{y->bufs[op.res_buf].ptr, y->bufs[op.res_buf].ch, op.res_off};
       const bool first = &op == &y->ops.front();
+      // 3x3 whose output feeds only the next op, a 1x1 (stride-2 conv -> C2f.cv1): one launch, no intermediate
+      const Op* nx = (&op + 1 <= &y->ops.back()) ? &op + 1 : nullptr;
+      const bool pair = !first && nx && nx->kind == kConv && op.f32_out < 0 && op.res_buf < 0 && nx->res_buf < 0 &&
+                        nx->f32_out < 0 && nx->in_buf == op.out_buf && nx->in_off == op.out_off && op.sole_consumer &&
+                        conv_post_ok(cw, y->weights[nx->conv]);
+      if (pair) {
+        const ConvWeights& pw = y->weights[nx->conv];
+        const Buf& ob2 = y->bufs[nx->out_buf];
+        rc = conv_forward(cw, in, n, H, W, Slice{ob2.ptr, ob2.ch, nx->out_off}, nullptr, Slice{}, op.act, stream, nullptr,
+                          &pw, nx->act);
+        const double px = (double)n * conv_out_dim(H, cw.ks, cw.stride) * conv_out_dim(W, cw.ks, cw.stride);
+        flops += (cw.flops_per_pixel() + pw.flops_per_pixel()) * px;
+        skip_next = true;
+        if (rc) return rc;
+        continue;
+      }
       rc = conv_forward(cw, in, n, H, W, out, f32, res, op.act, stream, first ? fused : nullptr);
       flops += cw.flops_per_pixel() * n * conv_out_dim(H, cw.ks, cw.stride) * conv_out_dim(W, cw.ks, cw.stride);
     } else if (op.kind == kPool) {

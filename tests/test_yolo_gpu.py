@@ -238,6 +238,38 @@ def test_fused_stem_equals_letterbox_then_network(gpu, h, w):
     det.close()
 
 
+@pytest.mark.parametrize("variant", ["n", "s"])
+def test_fused_3x3_1x1_pairs_are_bit_identical_to_separate_launches(gpu, variant, tmp_path):
+    """model.1 -> model.2.cv1 and model.3 -> model.4.cv1 run as ONE launch (the 1x1 consumes the 3x3's tile on chip).
+    Same fp16 rounding of the intermediate, same MFMA k order: the Detect maps must equal, bit for bit, those of a
+    process that runs every layer as its own launch (EIOKU_CONV_POST=0; the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from eioku_amd import detect as D, weights as W\n"
+        "from oracle import prng\n"
+        "f = torch.from_numpy(prng.synth_frames_bgr(41, 3, 96, 160)).cuda()\n"
+        "det = D.Yolov8Detector(%r, 80, W.random_state(%r, 80, seed=9))\n"
+        "x, _ = D.letterbox_f16(f)\n"
+        "box, cls = det.forward_raw(x)\n"
+        "np.savez(sys.argv[1], *[t.cpu().numpy() for t in box + cls])\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), variant, variant)
+    outs = {}
+    for flag in ("1", "0"):
+        path = tmp_path / f"heads_{flag}.npz"
+        env = dict(os.environ, EIOKU_CONV_POST=flag)
+        subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=env, timeout=300)
+        with np.load(path) as z:
+            outs[flag] = [z[k] for k in z.files]
+    assert len(outs["1"]) == 6
+    for a, b in zip(outs["1"], outs["0"]):
+        assert a.dtype == np.float32 and np.array_equal(a, b)
+
+
 def test_full_size_batch_split_invariance_and_pipelined_order(gpu):
     """BASELINE cfg2 size (64 x 640 x 640), size-independent properties: a frame's detections do not depend on
     which frames share its batch (the flattened-pixel kernels cut tiles ACROSS frame borders, the persistent ones
