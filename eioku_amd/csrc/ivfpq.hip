@@ -163,25 +163,83 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q,
   SmallTop<K> top;
   top.init();
   if (l >= 0) {
-    // LUT[j][c] = || (q - coarse[l])_j - pq[j][c] ||^2
-    for (int e = tid; e < m * 256; e += 256) {
-      const int j = e >> 8, c = e & 255;
-      float s = 0.f;
+    // residual query r = q - coarse[l] once, in LDS (behind the LUT; the merge area reuses both later)
+    float* rq = lut + (size_t)m * 256;
+    for (int t = tid; t < d; t += 256) rq[t] = q[(size_t)qi * d + t] - coarse[(size_t)l * d + t];
+    __syncthreads();
+    // LUT[j][c] = || r_j - pq[j][c] ||^2 : 16-byte loads, LB entries in flight per thread (one entry per loop
+    // iteration was 48 dependent L2 round trips per workgroup), same summation order as before
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int V4 = DSUB / 4, LB = 8;
+    const int nent = m * 256;
+    for (int e0 = 0; e0 < nent; e0 += 256 * LB) {
+      f32x4 rows[LB][V4];
 #pragma unroll
-      for (int t = 0; t < DSUB; ++t) {
-        const float r = q[(size_t)qi * d + j * DSUB + t] - coarse[(size_t)l * d + j * DSUB + t];
-        const float df = r - pq[((size_t)j * 256 + c) * DSUB + t];
-        s += df * df;
+      for (int b = 0; b < LB; ++b) {
+        int e = e0 + b * 256 + tid;
+        if (e >= nent) e = nent - 1;
+#pragma unroll
+        for (int t4 = 0; t4 < V4; ++t4) rows[b][t4] = *reinterpret_cast<const f32x4*>(pq + (size_t)e * DSUB + t4 * 4);
       }
-      lut[e] = s;
+#pragma unroll
+      for (int b = 0; b < LB; ++b) {
+        const int e = e0 + b * 256 + tid;
+        const int j = (e < nent ? e : nent - 1) >> 8;
+        float s = 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < V4; ++t4) {
+          const float* r = rq + j * DSUB + t4 * 4;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float df = r[t] - rows[b][t4][t];
+            s += df * df;
+          }
+        }
+        if (e < nent) lut[e] = s;
+      }
     }
     __syncthreads();
     const int off = offsets[l], sz = sizes[l];
-    for (int i = tid; i < sz; i += 256) {
-      const uint8_t* code = list_codes + (size_t)(off + i) * m;
-      float s = 0.f;
-      for (int j = 0; j < m; ++j) s += lut[j * 256 + code[j]];
-      top.insert(s, list_ids[off + i]);
+    const bool vec_codes = (m & 15) == 0 && m <= 64 && ((size_t)off * m & 15) == 0;  // rows stay 16-byte aligned
+    if (vec_codes) {
+      // codes and id of the NEXT vector are in flight while the current one is looked up
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      constexpr int MAXW = 4;  // m <= 64
+      const int nw = m >> 4;
+      u32x4 cn[MAXW];
+      long long idn = -1;
+      auto fetch = [&](int i) {
+        const int ii = i < sz ? i : sz - 1;
+        const uint8_t* code = list_codes + (size_t)(off + ii) * m;
+#pragma unroll
+        for (int w = 0; w < MAXW; ++w)
+          cn[w] = *reinterpret_cast<const u32x4*>(code + (w < nw ? w : 0) * 16);
+        idn = list_ids[off + ii];
+      };
+      if (sz > 0) fetch(tid);
+      for (int i = tid; i < sz; i += 256) {
+        u32x4 c[MAXW];
+#pragma unroll
+        for (int w = 0; w < MAXW; ++w) c[w] = cn[w];
+        const long long id = idn;
+        fetch(i + 256);
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < MAXW; ++w) {
+          if (w < nw) {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) s += lut[(w * 16 + b) * 256 + ((c[w][b >> 2] >> (8 * (b & 3))) & 0xFFu)];
+          }
+        }
+        top.insert(s, id);
+      }
+    } else {
+      for (int i = tid; i < sz; i += 256) {
+        const uint8_t* code = list_codes + (size_t)(off + i) * m;
+        float s = 0.f;
+        for (int j = 0; j < m; ++j) s += lut[j * 256 + code[j]];
+        top.insert(s, list_ids[off + i]);
+      }
     }
   }
   __syncthreads();
@@ -337,7 +395,7 @@ int eioku_ivfpq_scan(const float* q_dev, int nq, int d, int m, const long long* 
   if (nq == 0) return EIOKU_OK;
   hipStream_t stream = (hipStream_t)stream_;
   const int K = k <= 16 ? 16 : 32;
-  size_t lds = (size_t)m * 256 * 4;
+  size_t lds = (size_t)m * 256 * 4 + (size_t)d * 4;  // LUT + residual query
   const size_t merge = (size_t)256 * K * 12;
   if (merge > lds) lds = merge;
   EIOKU_REQUIRE(lds <= 150 * 1024, "m=%d needs %zu bytes of LDS", m, lds);
