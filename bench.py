@@ -36,7 +36,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (BASELINE cfg2: 64)")
     ap.add_argument("--height", type=int, default=640)

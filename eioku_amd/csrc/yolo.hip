@@ -283,6 +283,7 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
             int part = 0) {
   double flops = 0;
   bool skip_next = false;
+  int pool_skip = 0;
   for (const Op& op : y->ops) {
     const bool is_first = &op == &y->ops.front();
     if ((part == 1 && !is_first) || (part == 2 && is_first)) continue;
@@ -326,7 +327,25 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
       flops += cw.flops_per_pixel() * n * conv_out_dim(H, cw.ks, cw.stride) * conv_out_dim(W, cw.ks, cw.stride);
     } else if (op.kind == kPool) {
       const Buf& ob = y->bufs[op.out_buf];
-      rc = maxpool5_forward(in, Slice{ob.ptr, ob.ch, op.out_off}, n, H, W, op.in_ch, stream);
+      // SPPF: pool -> pool -> pool, each reading the previous one's slice: one launch when the plane fits in LDS
+      const Op* p1 = &op + 1 <= &y->ops.back() ? &op + 1 : nullptr;
+      const Op* p2 = &op + 2 <= &y->ops.back() ? &op + 2 : nullptr;
+      const int step = op.out_off - op.in_off;
+      const bool chain = pool_skip == 0 && p1 && p2 && p1->kind == kPool && p2->kind == kPool && p1->in_buf == op.out_buf &&
+                         p2->in_buf == op.out_buf && p1->out_buf == op.out_buf && p2->out_buf == op.out_buf &&
+                         p1->in_off == op.out_off && p2->in_off == p1->out_off && p1->out_off - p1->in_off == step &&
+                         p2->out_off - p2->in_off == step && p1->in_ch == op.in_ch && p2->in_ch == op.in_ch &&
+                         op.in_buf == op.out_buf && (size_t)H * W * 32 <= 128 * 1024;
+      if (pool_skip > 0) {
+        --pool_skip;
+        continue;
+      }
+      if (chain) {
+        rc = sppf_pools_forward(in, Slice{ob.ptr, ob.ch, op.out_off}, step, n, H, W, op.in_ch, stream);
+        pool_skip = 2;
+      } else {
+        rc = maxpool5_forward(in, Slice{ob.ptr, ob.ch, op.out_off}, n, H, W, op.in_ch, stream);
+      }
     } else {
       const Buf& ob = y->bufs[op.out_buf];
       rc = upsample2x_forward(in, Slice{ob.ptr, ob.ch, op.out_off}, n, H, W, op.in_ch, stream);

@@ -43,6 +43,8 @@ int letterbox_forward(const uint8_t* bgr, int n, const LetterboxPlan& p, __half*
 
 // K5. 5x5 stride-1 max pool (pad 2, -inf) on a channel slice -> another slice (SPPF chain).
 int maxpool5_forward(Slice in, Slice out, int N, int H, int W, int C, hipStream_t stream);
+// K5. three chained pools (SPPF): out, out + out_step, out + 2*out_step channels receive pool, pool^2, pool^3 of `in`.
+int sppf_pools_forward(Slice in, Slice out, int out_step, int N, int H, int W, int C, hipStream_t stream);
 // K5. nearest 2x upsample of a slice into a slice of a (2H,2W) buffer (fused concat write).
 int upsample2x_forward(Slice in, Slice out, int N, int H, int W, int C, hipStream_t stream);
 

@@ -72,6 +72,34 @@ __global__ __launch_bounds__(256) void k_letterbox(LbArgs a) {
 // ---------------------------------------------------------------------------------------------
 // K5 glue
 // ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sppf_pools(const __half* in, int in_cs, __half* out, int out_cs, int out_step,
+                                                    int H, int W) {
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_pool[];
+  half8* a = reinterpret_cast<half8*>(smem_pool);
+  half8* b = a + H * W;
+  const int u = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, npx = H * W;
+  const size_t base = (size_t)n * npx;
+  for (int p = tid; p < npx; p += 256) a[p] = *reinterpret_cast<const half8*>(in + (base + p) * in_cs + u * 8);
+  __syncthreads();
+  const _Float16 ninf = -__builtin_inff16();
+  for (int stage = 0; stage < 3; ++stage) {
+    const half8* src = (stage & 1) ? b : a;
+    half8* dst = (stage & 1) ? a : b;
+    for (int p = tid; p < npx; p += 256) {
+      const int y = p / W, x = p - y * W;
+      half8 m = {ninf, ninf, ninf, ninf, ninf, ninf, ninf, ninf};
+      const int y0 = y - 2 < 0 ? 0 : y - 2, y1 = y + 2 >= H ? H - 1 : y + 2;
+      const int x0 = x - 2 < 0 ? 0 : x - 2, x1 = x + 2 >= W ? W - 1 : x + 2;
+      for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) m = __builtin_elementwise_max(m, src[yy * W + xx]);
+      if (stage < 2) dst[p] = m;
+      *reinterpret_cast<half8*>(out + (base + p) * out_cs + stage * out_step + u * 8) = m;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_maxpool5(const __half* in, int in_cs, __half* out, int out_cs,
                                                   int N, int H, int W, int C8) {
   const long long total = (long long)N * H * W * C8;
@@ -340,6 +368,26 @@ int letterbox_forward(const uint8_t* bgr, int n, const LetterboxPlan& p, __half*
   LbArgs a{bgr, out, n, p.src_h, p.src_w, p.new_h, p.new_w, p.top, p.left, p.out_h, p.out_w, p.mode,
            p.xofs, p.yofs, p.xalpha, p.ybeta};
   hipLaunchKernelGGL(k_letterbox, dim3(blocks_for((long long)n * p.out_h * p.out_w)), dim3(256), 0, stream, a);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+// SPPF's three chained 5x5 pools in one launch: a workgroup keeps one (frame, 8-channel unit) plane in LDS, so
+// the chain y1 = pool(x), y2 = pool(y1), y3 = pool(y2) never re-reads HBM (three ~14 us launches at 20x20 -> one).
+int sppf_pools_forward(Slice in, Slice out, int out_step, int N, int H, int W, int C, hipStream_t stream) {
+  EIOKU_REQUIRE(C % 8 == 0 && in.cstride % 8 == 0 && in.coff % 8 == 0 && out.cstride % 8 == 0 && out.coff % 8 == 0 &&
+                    out_step % 8 == 0, "maxpool slices must be 8-channel aligned");
+  EIOKU_REQUIRE((size_t)H * W * 32 <= 128 * 1024, "plane %dx%d too large for the fused SPPF pools", H, W);
+  if (N == 0) return EIOKU_OK;
+  const size_t lds = (size_t)H * W * 32;
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sppf_pools), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+    attr = lds;
+  }
+  hipLaunchKernelGGL(k_sppf_pools, dim3((unsigned)(C / 8), (unsigned)N), dim3(256), lds, stream, in.ptr + in.coff, in.cstride,
+                     out.ptr + out.coff, out.cstride, out_step, H, W);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }
