@@ -10,15 +10,40 @@ def level(name):
     return {0:0,1:1,2:2,3:2,4:3,5:3,6:4,7:4,8:5,9:5,12:4,15:3,16:3,18:4,19:4,21:5}[i]
 fs = sorted(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)
 rows = [r for r in csv.DictReader(open(fs[-1])) if 'k_conv' in r['Kernel_Name']]
-last = rows[-len(tab):]
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+# a launch whose kernel carries POST = true (5th template argument) also ran the NEXT layer (3x3 + 1x1 pair): walk the
+# trace backwards from its end, one forward's worth of layers
+def is_pair(r):
+    m = re.search(r'k_conv3x3_persist<([^>]*)>', r['Kernel_Name'])
+    return bool(m) and m.group(1).replace(' ', '').endswith(',true') and m.group(1).count(',') == 4
+pairs_layers = {'model.1.conv', 'model.3.conv'}
+last, i = [], len(rows) - 1
+need = len(tab)
+while need > 0 and i >= 0:
+    last.append(rows[i]); need -= 2 if is_pair(rows[i]) else 1; i -= 1
+last.reverse()
 tot_t = tot_b = tot_f = 0
 print(f"{'layer':28s} {'shape':22s} {'kernel':28s} {'grid':>9s} {'us':>7s} {'MB':>7s} {'GB/s':>6s} {'TF/s':>6s}")
-for (name, cout, cin, k, s), r in zip(tab, last):
+it = iter(last)
+skip = False
+for (name, cout, cin, k, s) in tab:
     lv = level(name); hin = H >> lv; hout = hin // s
+    if skip:  # ran inside the previous row's launch: its bytes are the output only, its time is already counted
+        skip = False
+        px_out = batch * hout * hout
+        by = px_out * cout * 2; fl = 2.0 * px_out * cout * cin * k * k
+        tot_b += by; tot_f += fl
+        print(f"{name:28s} {cin:4d}->{cout:4d} k{k}s{s} @{hout:3d} (fused into the launch above; +{by/1e6:.1f} MB out, +{fl/1e9:.1f} GFLOP)")
+        continue
+    r = next(it)
+    fused = is_pair(r)
     cin_eff = 8 if name == 'model.0.conv' else cin
     px_in, px_out = batch * hin * hin, batch * hout * hout
     obytes = 4 if re.search(r'cv[23]\.\d\.2$', name) else 2
-    by = px_in * cin_eff * 2 + px_out * cout * obytes
+    by = px_in * cin_eff * 2 + (0 if fused else px_out * cout * obytes)
+    if name == 'model.0.conv' and 'k_conv3x3_c8' in r['Kernel_Name'] and not re.search(r'c8<\d+, \d+, 0>', r['Kernel_Name']):
+        by = px_in * 3 + px_out * cout * obytes  # fused letterbox: the stem reads the BGR u8 frames
+    skip = fused
     fl = 2.0 * px_out * cout * cin * k * k
     us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     kn = re.search(r'(k_conv\w+<[^>]*>)', r['Kernel_Name']).group(1)
