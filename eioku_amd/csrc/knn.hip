@@ -533,7 +533,9 @@ int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D,
   const int K = k == 1 ? 1 : (k <= 16 ? 16 : 32);  // k == 1: coarse assignment (k-means / IVF), a single compare per row
   const int qtiles = (nq + kQT - 1) / kQT;
   // wide: 4 query tiles share every staged row tile (one HBM pass per 128 queries)
-  const bool wide = qtiles > 1;
+  // two query tiles: two narrow passes (all 4 waves of every workgroup busy, 2 x 3.6 ms at 10 M x 384) beat one
+  // wide pass with half of its waves idle (11.4 ms)
+  const bool wide = qtiles > 2;
   const int ygroups = wide ? (qtiles + kWaves - 1) / kWaves : qtiles;
   // One workgroup is resident per CU (the query tile fills the register file), and a slab that is too
   // short never leaves the phase where most rows still enter some lane's top-K (the insertion path runs
