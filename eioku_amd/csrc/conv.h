@@ -56,7 +56,10 @@ bool fused_input_ok(const ConvWeights& cw, const FusedInput& f, Slice res, const
 bool conv_post_ok(const ConvWeights& cw, const ConvWeights& post);
 int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out, float* out_f32,
                  Slice res, int act, hipStream_t stream, const FusedInput* fused = nullptr,
-                 const ConvWeights* post = nullptr, int post_act = kActSiLU);
+                 const ConvWeights* post = nullptr, int post_act = kActSiLU, unsigned long long* clsmax = nullptr);
+// `clsmax` (1x1, no activation, one cout tile): instead of the output tensor, per pixel one 64-bit word
+// (argmax channel << 32 | float bits of max_c(conv + bias)); ties go to the lower channel.
+bool conv_clsmax_ok(const ConvWeights& cw, int act);
 
 inline int conv_out_dim(int x, int ks, int stride) { return (x + 2 * (ks / 2) - ks) / stride + 1; }
 

@@ -44,6 +44,9 @@ struct ConvArgs {
   const float* post_bias;
   __half* post_out;
   int post_out_cs, post_cout, post_act;
+  // class-max epilogue (1x1, one cout tile, no activation): per pixel {max_c (conv + bias), argmax} instead of the
+  // Cout-wide fp32 row -- what the Detect decode needs from the class branch, 8 bytes instead of 4*nc
+  unsigned long long* clsmax;
 };
 
 // x / d for 0 <= x < 2^24 (exact int->float) with a precomputed 1.0f/d: one multiply and a +-1 fix-up instead
@@ -228,12 +231,46 @@ __global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (a.clsmax) {
+      // lane (r, u) holds classes f*16 + u*4 + j of pixel r: ascending class order inside the lane (strict > keeps
+      // the first maximum), then the 4 lanes of the pixel combine (ties: lower class), exactly k_decode's rule
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const long long p = g * 32 + m * 16 + r;
-      if (p >= npix) continue;
+      for (int m = 0; m < 2; ++m) {
+        float best = -INFINITY;
+        int bj = 0x7FFFFFFF;
 #pragma unroll
-      for (int f = 0; f < NF; ++f) store_frag(a, acc[m][f], (size_t)p, co_tile * ROWS + f * 16 + u * 4, biasr[f]);
+        for (int f = 0; f < NF; ++f) {
+          const float bb[4] = {biasr[f].x, biasr[f].y, biasr[f].z, biasr[f].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = f * 16 + u * 4 + j;
+            const float v = acc[m][f][j] + bb[j];
+            if (c < a.Cout && v > best) {
+              best = v;
+              bj = c;
+            }
+          }
+        }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+          const float ob = __shfl_xor(best, off, 64);
+          const int oj = __shfl_xor(bj, off, 64);
+          if (ob > best || (ob == best && oj < bj)) {
+            best = ob;
+            bj = oj;
+          }
+        }
+        const long long p = g * 32 + m * 16 + r;
+        if (u == 0 && p < npix) a.clsmax[p] = ((unsigned long long)(unsigned)bj << 32) | __float_as_uint(best);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const long long p = g * 32 + m * 16 + r;
+        if (p >= npix) continue;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) store_frag(a, acc[m][f], (size_t)p, co_tile * ROWS + f * 16 + u * 4, biasr[f]);
+      }
     }
   }
 }
@@ -1264,6 +1301,11 @@ void conv_weights_destroy(ConvWeights* cw) {
   cw->d_b = nullptr;
 }
 
+bool conv_clsmax_ok(const ConvWeights& cw, int act) {
+  static const bool off = getenv("EIOKU_CLSMAX") && atoi(getenv("EIOKU_CLSMAX")) == 0;
+  return !off && cw.ks == 1 && cw.ntiles == 1 && act == kActNone;
+}
+
 bool conv_post_ok(const ConvWeights& cw, const ConvWeights& post) {
   static const bool off = getenv("EIOKU_CONV_POST") && atoi(getenv("EIOKU_CONV_POST")) == 0;
   if (off) return false;
@@ -1281,11 +1323,13 @@ bool fused_input_ok(const ConvWeights& cw, const FusedInput& f, Slice res, const
 }
 
 int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out, float* out_f32,
-                 Slice res, int act, hipStream_t stream, const FusedInput* fused, const ConvWeights* post, int post_act) {
+                 Slice res, int act, hipStream_t stream, const FusedInput* fused, const ConvWeights* post, int post_act,
+                 unsigned long long* clsmax) {
   EIOKU_REQUIRE(cw.d_w, "conv weights not created");
+  EIOKU_REQUIRE(!clsmax || conv_clsmax_ok(cw, act), "class-max output needs a 1x1 conv with one cout tile and no activation");
   EIOKU_REQUIRE(!post || (post->d_w && conv_post_ok(cw, *post) && !res.ptr && !out_f32 && !fused && out.ptr),
                 "this pair of layers cannot run as one launch");
-  EIOKU_REQUIRE((in.ptr || fused) && (out.ptr || out_f32), "NULL tensor");
+  EIOKU_REQUIRE((in.ptr || fused) && (out.ptr || out_f32 || clsmax), "NULL tensor");
   EIOKU_REQUIRE(!fused || fused_input_ok(cw, *fused, res, out_f32), "layer cannot read a fused letterbox input");
   EIOKU_REQUIRE(in.cstride % 8 == 0 && in.coff % 8 == 0, "input slice must be 8-channel aligned");
   // cout < 4 (the 1-class face head) only ever takes the scalar store path
@@ -1321,6 +1365,7 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
   a.post_out_cs = out.cstride;
   a.post_cout = post ? post->cout : 0;
   a.post_act = post_act;
+  a.clsmax = clsmax;
   prof_start(EIOKU_PROF_CONV, stream);
   int rc = EIOKU_OK;
   bool handled = false;

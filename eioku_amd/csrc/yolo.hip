@@ -60,6 +60,8 @@ struct eioku_yolo {
   int cur_n = 0, cur_h = 0, cur_w = 0;
   float* head[6] = {};  // box P3,P4,P5 ; cls P3,P4,P5 (fp32)
   size_t head_cap[6] = {};
+  unsigned long long* clsmax[3] = {};  // per anchor (argmax << 32 | max-logit bits): detect()'s class branch output
+  size_t clsmax_cap[3] = {};
   Cand* cands = nullptr;  // dense [N][A] followed by keys [N][A]
   size_t cands_cap = 0;
   int32_t* counts = nullptr;  // [N] cand counts + [N] det counts
@@ -267,6 +269,8 @@ int prepare(eioku_yolo* y, int n, int h, int w) {
     if (rc) return rc;
     rc = ensure(&y->head[3 + l], &y->head_cap[3 + l], px * y->nc * sizeof(float));
     if (rc) return rc;
+    rc = ensure(&y->clsmax[l], &y->clsmax_cap[l], px * sizeof(unsigned long long));
+    if (rc) return rc;
   }
   int rc = ensure(&y->cands, &y->cands_cap, (size_t)n * A * (sizeof(Cand) + sizeof(unsigned long long)));
   if (rc) return rc;
@@ -280,7 +284,7 @@ int prepare(eioku_yolo* y, int n, int h, int w) {
 
 // part: 0 = every op, 1 = the first op only, 2 = all but the first
 int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedInput* fused, double* flops_out,
-            int part = 0) {
+            int part = 0, bool clsmax = false) {
   double flops = 0;
   bool skip_next = false;
   int pool_skip = 0;
@@ -323,7 +327,11 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
         if (rc) return rc;
         continue;
       }
-      rc = conv_forward(cw, in, n, H, W, out, f32, res, op.act, stream, first ? fused : nullptr);
+      if (clsmax && op.f32_out >= 3 && conv_clsmax_ok(cw, op.act))  // class branch: max / argmax words, no logit map
+        rc = conv_forward(cw, in, n, H, W, Slice{}, nullptr, Slice{}, op.act, stream, nullptr, nullptr, kActNone,
+                          y->clsmax[op.f32_out - 3]);
+      else
+        rc = conv_forward(cw, in, n, H, W, out, f32, res, op.act, stream, first ? fused : nullptr);
       flops += cw.flops_per_pixel() * n * conv_out_dim(H, cw.ks, cw.stride) * conv_out_dim(W, cw.ks, cw.stride);
     } else if (op.kind == kPool) {
       const Buf& ob = y->bufs[op.out_buf];
@@ -356,7 +364,8 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
   return EIOKU_OK;
 }
 
-int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedInput* fused = nullptr) {
+int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedInput* fused = nullptr,
+                bool clsmax = false) {
   for (size_t i = 0; i < y->set.size(); ++i)
     EIOKU_REQUIRE(y->set[i], "conv %zu (%s) has no weights", i, y->names[i].c_str());
   // opt-in (EIOKU_GRAPH=1): on ROCm 7.2 / MI355X replaying the forward as a graph measured 3.07 ms per bench step
@@ -364,7 +373,7 @@ int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const Fu
   static const bool graphs = getenv("EIOKU_GRAPH") && atoi(getenv("EIOKU_GRAPH")) == 1;
   auto& g = y->net_graph;
   // eager whenever the per-launch event hooks are on (events recorded inside a graph cannot be read back)
-  if (!graphs || prof_enabled() || n == 0) return run_ops(y, n, h, w, stream, fused, &y->conv_flops_last);
+  if (!graphs || prof_enabled() || n == 0 || clsmax) return run_ops(y, n, h, w, stream, fused, &y->conv_flops_last, 0, clsmax);
   // a fused stem reads the CALLER's frames: it stays an ordinary launch so that the graph only ever points at
   // this handle's own buffers and weights
   double flops0 = 0;
@@ -446,6 +455,8 @@ void eioku_yolo_destroy(eioku_yolo* y) {
     if (b.ptr) (void)hipFree(b.ptr);
   for (int i = 0; i < 6; ++i)
     if (y->head[i]) (void)hipFree(y->head[i]);
+  for (int i = 0; i < 3; ++i)
+    if (y->clsmax[i]) (void)hipFree(y->clsmax[i]);
   if (y->cands) (void)hipFree(y->cands);
   if (y->counts) (void)hipFree(y->counts);
   if (y->dets) (void)hipFree(y->dets);
@@ -590,7 +601,12 @@ int eioku_yolo_detect(eioku_yolo* y, const uint8_t* bgr, int n, int h, int w, co
     rc = letterbox_forward(d_bgr, n, p, y->bufs[y->in_buf].ptr, stream);
     if (rc) return rc;
   }
-  rc = run_network(y, n, p.out_h, p.out_w, stream, fuse ? &fi : nullptr);
+  // the class branch hands decode {max logit, argmax} per anchor (8 B) instead of the nc-wide fp32 rows, when its
+  // last conv can (one cout tile: nc <= 128)
+  bool cm = true;
+  for (const Op& op : y->ops)
+    if (op.kind == kConv && op.f32_out >= 3) cm = cm && conv_clsmax_ok(y->weights[op.conv], op.act);
+  rc = run_network(y, n, p.out_h, p.out_w, stream, fuse ? &fi : nullptr, cm);
   if (rc) return rc;
 
   int Hl[3], Wl[3], A = 0;
@@ -604,7 +620,8 @@ int eioku_yolo_detect(eioku_yolo* y, const uint8_t* bgr, int n, int h, int w, co
   EIOKU_HIP_CHECK(hipMemsetAsync(y->counts, 0, (size_t)n * 2 * sizeof(int32_t), stream));
   const float* box[3] = {y->head[0], y->head[1], y->head[2]};
   const float* cls[3] = {y->head[3], y->head[4], y->head[5]};
-  rc = decode_forward(box, cls, n, Hl, Wl, y->nc, conf, y->cands, y->counts, A, stream);
+  const unsigned long long* cmw[3] = {y->clsmax[0], y->clsmax[1], y->clsmax[2]};
+  rc = decode_forward(box, cm ? nullptr : cls, n, Hl, Wl, y->nc, conf, y->cands, y->counts, A, stream, cm ? cmw : nullptr);
   if (rc) return rc;
   ScaleParams sp;
   sp.gain = gain;

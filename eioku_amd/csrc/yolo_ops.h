@@ -53,7 +53,8 @@ int upsample2x_forward(Slice in, Slice out, int N, int H, int W, int C, hipStrea
 //   cands: [N][max_cand], counts: [N] (must be zeroed by the caller).
 int decode_forward(const float* const box[3], const float* const cls[3], int N, const int Hl[3],
                    const int Wl[3], int nc, float conf_thres, Cand* cands, int32_t* counts,
-                   int max_cand, hipStream_t stream);
+                   int max_cand, hipStream_t stream, const unsigned long long* const clsmax[3] = nullptr);
+//   clsmax[l] (optional, then cls may be null): [N,Hl,Wl] words (argmax << 32 | max-logit bits) from the class conv.
 
 // K7. per-image: sort by (conf desc, anchor asc), class-aware greedy NMS (IoU > thr suppresses),
 // keep <= max_det, then scale_boxes to the original frame and clip.

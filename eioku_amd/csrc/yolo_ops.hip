@@ -159,6 +159,7 @@ struct DecArgs {
   Cand* cands;      // dense [N][A]
   unsigned long long* keys;  // compact [N][A]
   int32_t* counts;
+  const unsigned long long* cm[3];  // class-max words per level (k_decode_cm) or null
 };
 
 __device__ __forceinline__ float dfl_side(const float* __restrict__ l) {
@@ -217,6 +218,52 @@ __global__ __launch_bounds__(256) void k_decode(DecArgs a) {
     if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
   }
   if (sub != 0) return;
+  const float conf = 1.0f / (1.0f + expf(-best));
+  if (!(conf > a.conf)) return;
+  const float* bl = a.box[lvl] + pix * 64;
+  float side[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float l[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(bl + s * 16 + q * 4);
+      l[q * 4] = v.x; l[q * 4 + 1] = v.y; l[q * 4 + 2] = v.z; l[q * 4 + 3] = v.w;
+    }
+    side[s] = dfl_side(l);
+  }
+  const float stride = (float)(8 << lvl);
+  const float ax = (float)(loc % W) + 0.5f, ay = (float)(loc / W) + 0.5f;
+  // dist2bbox(xywh=True): x1y1 = anchor - lt ; x2y2 = anchor + rb ; c = (x1y1+x2y2)/2 ; wh = x2y2-x1y1
+  const float bx1 = ax - side[0], by1 = ay - side[1], bx2 = ax + side[2], by2 = ay + side[3];
+  const float cx = ((bx1 + bx2) / 2.0f) * stride, cy = ((by1 + by2) / 2.0f) * stride;
+  const float w = (bx2 - bx1) * stride, h = (by2 - by1) * stride;
+  // xywh2xyxy inside non_max_suppression
+  const float hw = w / 2.0f, hh = h / 2.0f;
+  Cand c;
+  c.x1 = cx - hw; c.y1 = cy - hh; c.x2 = cx + hw; c.y2 = cy + hh;
+  c.conf = conf; c.cls = bj; c.anchor = an; c.pad = 0;
+  a.cands[(size_t)n * a.A + an] = c;
+  const int pos = atomicAdd(&a.counts[n], 1);
+  a.keys[(size_t)n * a.A + pos] =
+      ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)an);
+}
+
+// Same decode, but the class branch arrives as per-anchor {max logit, argmax} words written by the class conv's
+// own epilogue (conv.hip, clsmax): one thread per anchor, 8 bytes instead of the 4*nc-byte logit row.
+__global__ __launch_bounds__(256) void k_decode_cm(DecArgs a) {
+  const long long total = (long long)a.N * a.A;
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i / a.A);
+  const int an = (int)(i % a.A);
+  const int lvl = an >= a.A0[2] ? 2 : (an >= a.A0[1] ? 1 : 0);
+  const int loc = an - a.A0[lvl];
+  const int W = a.W[lvl], H = a.H[lvl];
+  const size_t pix = (size_t)n * H * W + loc;
+  const unsigned long long word = a.cm[lvl][pix];
+  const float best = __uint_as_float((unsigned)(word & 0xFFFFFFFFull));
+  const int bj = (int)(word >> 32);
   const float conf = 1.0f / (1.0f + expf(-best));
   if (!(conf > a.conf)) return;
   const float* bl = a.box[lvl] + pix * 64;
@@ -414,13 +461,14 @@ int upsample2x_forward(Slice in, Slice out, int N, int H, int W, int C, hipStrea
 
 int decode_forward(const float* const box[3], const float* const cls[3], int N, const int Hl[3],
                    const int Wl[3], int nc, float conf_thres, Cand* cands, int32_t* counts, int max_cand,
-                   hipStream_t stream) {
+                   hipStream_t stream, const unsigned long long* const clsmax[3]) {
   if (N == 0) return EIOKU_OK;
   DecArgs a;
   int A = 0;
   for (int l = 0; l < 3; ++l) {
     a.box[l] = box[l];
-    a.cls[l] = cls[l];
+    a.cls[l] = cls ? cls[l] : nullptr;
+    a.cm[l] = clsmax ? clsmax[l] : nullptr;
     a.H[l] = Hl[l];
     a.W[l] = Wl[l];
     a.A0[l] = A;
@@ -435,7 +483,8 @@ int decode_forward(const float* const box[3], const float* const cls[3], int N, 
   // keys live right after the dense candidate array (see yolo.hip workspace layout)
   a.keys = reinterpret_cast<unsigned long long*>(cands + (size_t)N * A);
   a.counts = counts;
-  hipLaunchKernelGGL(k_decode, dim3(blocks_for((long long)N * A * 16)), dim3(256), 0, stream, a);
+  if (clsmax) hipLaunchKernelGGL(k_decode_cm, dim3(blocks_for((long long)N * A)), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(k_decode, dim3(blocks_for((long long)N * A * 16)), dim3(256), 0, stream, a);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }
