@@ -62,6 +62,8 @@ struct eioku_yolo {
   size_t head_cap[6] = {};
   unsigned long long* clsmax[3] = {};  // per anchor (argmax << 32 | max-logit bits): detect()'s class branch output
   size_t clsmax_cap[3] = {};
+  int32_t* lvl = nullptr;  // lazy box branch: [N][A] per-level lists of passing anchors, then [N][3] counts
+  size_t lvl_cap = 0;
   Cand* cands = nullptr;  // dense [N][A] followed by keys [N][A]
   size_t cands_cap = 0;
   int32_t* counts = nullptr;  // [N] cand counts + [N] det counts
@@ -276,6 +278,8 @@ int prepare(eioku_yolo* y, int n, int h, int w) {
   if (rc) return rc;
   rc = ensure(&y->counts, &y->counts_cap, (size_t)n * 2 * sizeof(int32_t));
   if (rc) return rc;
+  rc = ensure(&y->lvl, &y->lvl_cap, ((size_t)n * A + (size_t)n * 3) * sizeof(int32_t));
+  if (rc) return rc;
   y->cur_n = n;
   y->cur_h = h;
   y->cur_w = w;
@@ -284,7 +288,7 @@ int prepare(eioku_yolo* y, int n, int h, int w) {
 
 // part: 0 = every op, 1 = the first op only, 2 = all but the first
 int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedInput* fused, double* flops_out,
-            int part = 0, bool clsmax = false) {
+            int part = 0, bool clsmax = false, bool lazybox = false) {
   double flops = 0;
   bool skip_next = false;
   int pool_skip = 0;
@@ -327,6 +331,7 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
         if (rc) return rc;
         continue;
       }
+      if (lazybox && op.f32_out >= 0 && op.f32_out < 3) continue;  // box branch's last conv: evaluated by decode, per anchor
       if (clsmax && op.f32_out >= 3 && conv_clsmax_ok(cw, op.act))  // class branch: max / argmax words, no logit map
         rc = conv_forward(cw, in, n, H, W, Slice{}, nullptr, Slice{}, op.act, stream, nullptr, nullptr, kActNone,
                           y->clsmax[op.f32_out - 3]);
@@ -365,7 +370,7 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
 }
 
 int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedInput* fused = nullptr,
-                bool clsmax = false) {
+                bool clsmax = false, bool lazybox = false) {
   for (size_t i = 0; i < y->set.size(); ++i)
     EIOKU_REQUIRE(y->set[i], "conv %zu (%s) has no weights", i, y->names[i].c_str());
   // opt-in (EIOKU_GRAPH=1): on ROCm 7.2 / MI355X replaying the forward as a graph measured 3.07 ms per bench step
@@ -373,7 +378,7 @@ int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const Fu
   static const bool graphs = getenv("EIOKU_GRAPH") && atoi(getenv("EIOKU_GRAPH")) == 1;
   auto& g = y->net_graph;
   // eager whenever the per-launch event hooks are on (events recorded inside a graph cannot be read back)
-  if (!graphs || prof_enabled() || n == 0 || clsmax) return run_ops(y, n, h, w, stream, fused, &y->conv_flops_last, 0, clsmax);
+  if (!graphs || prof_enabled() || n == 0 || clsmax) return run_ops(y, n, h, w, stream, fused, &y->conv_flops_last, 0, clsmax, lazybox);
   // a fused stem reads the CALLER's frames: it stays an ordinary launch so that the graph only ever points at
   // this handle's own buffers and weights
   double flops0 = 0;
@@ -457,6 +462,7 @@ void eioku_yolo_destroy(eioku_yolo* y) {
     if (y->head[i]) (void)hipFree(y->head[i]);
   for (int i = 0; i < 3; ++i)
     if (y->clsmax[i]) (void)hipFree(y->clsmax[i]);
+  if (y->lvl) (void)hipFree(y->lvl);
   if (y->cands) (void)hipFree(y->cands);
   if (y->counts) (void)hipFree(y->counts);
   if (y->dets) (void)hipFree(y->dets);
@@ -606,7 +612,23 @@ int eioku_yolo_detect(eioku_yolo* y, const uint8_t* bgr, int n, int h, int w, co
   bool cm = true;
   for (const Op& op : y->ops)
     if (op.kind == kConv && op.f32_out >= 3) cm = cm && conv_clsmax_ok(y->weights[op.conv], op.act);
-  rc = run_network(y, n, p.out_h, p.out_w, stream, fuse ? &fi : nullptr, cm);
+  // ... and then only the anchors that pass the threshold need their 64 DFL logits: the box branch's last 1x1 conv
+  // is evaluated by decode for those (one 64-row weight tile, whole 32-channel chunks)
+  static const bool lazy_off = getenv("EIOKU_LAZY_BOX") && atoi(getenv("EIOKU_LAZY_BOX")) == 0;
+  bool lazy = cm && !lazy_off;
+  LazyBox lbx{};
+  for (const Op& op : y->ops)
+    if (op.kind == kConv && op.f32_out >= 0 && op.f32_out < 3) {
+      const ConvWeights& cw = y->weights[op.conv];
+      lazy = lazy && cw.ks == 1 && cw.ntiles == 1 && cw.nf == 4 && cw.cout == 64 && cw.cin % 32 == 0 && op.act == kActNone &&
+             op.res_buf < 0 && (lbx.in_cs == 0 || (lbx.in_cs == y->bufs[op.in_buf].ch && lbx.nchunks == cw.nchunks));
+      lbx.in[op.f32_out] = y->bufs[op.in_buf].ptr + op.in_off;
+      lbx.wgt[op.f32_out] = reinterpret_cast<const uint4*>(cw.d_w);
+      lbx.bias[op.f32_out] = cw.d_b;
+      lbx.in_cs = y->bufs[op.in_buf].ch;
+      lbx.nchunks = cw.nchunks;
+    }
+  rc = run_network(y, n, p.out_h, p.out_w, stream, fuse ? &fi : nullptr, cm, lazy);
   if (rc) return rc;
 
   int Hl[3], Wl[3], A = 0;
@@ -621,7 +643,14 @@ int eioku_yolo_detect(eioku_yolo* y, const uint8_t* bgr, int n, int h, int w, co
   const float* box[3] = {y->head[0], y->head[1], y->head[2]};
   const float* cls[3] = {y->head[3], y->head[4], y->head[5]};
   const unsigned long long* cmw[3] = {y->clsmax[0], y->clsmax[1], y->clsmax[2]};
-  rc = decode_forward(box, cm ? nullptr : cls, n, Hl, Wl, y->nc, conf, y->cands, y->counts, A, stream, cm ? cmw : nullptr);
+  if (lazy) {
+    int32_t* lvl_counts = y->lvl + (size_t)n * A;
+    EIOKU_HIP_CHECK(hipMemsetAsync(lvl_counts, 0, (size_t)n * 3 * sizeof(int32_t), stream));
+    float* boxw[3] = {y->head[0], y->head[1], y->head[2]};
+    rc = decode_lazy_forward(boxw, cmw, lbx, n, Hl, Wl, y->nc, conf, y->cands, y->counts, y->lvl, lvl_counts, A, stream);
+  } else {
+    rc = decode_forward(box, cm ? nullptr : cls, n, Hl, Wl, y->nc, conf, y->cands, y->counts, A, stream, cm ? cmw : nullptr);
+  }
   if (rc) return rc;
   ScaleParams sp;
   sp.gain = gain;

@@ -56,6 +56,20 @@ int decode_forward(const float* const box[3], const float* const cls[3], int N, 
                    int max_cand, hipStream_t stream, const unsigned long long* const clsmax[3] = nullptr);
 //   clsmax[l] (optional, then cls may be null): [N,Hl,Wl] words (argmax << 32 | max-logit bits) from the class conv.
 
+// K6 with a lazy box branch (detect()): `clsmax` words decide which anchors pass; only for those the box branch's
+// last 1x1 conv (lb: its fp16 input per level, packed weights with ONE 64-row tile, bias) is evaluated -- into the
+// same rows of box[l] the dense conv would have written -- and decoded.  lvl_list [N][A] / lvl_counts [N][3]
+// (zeroed by the caller) are workspace.
+struct LazyBox {
+  const __half* in[3];
+  const uint4* wgt[3];
+  const float* bias[3];
+  int in_cs, nchunks;
+};
+int decode_lazy_forward(float* const box[3], const unsigned long long* const clsmax[3], const LazyBox& lb, int N,
+                        const int Hl[3], const int Wl[3], int nc, float conf_thres, Cand* cands, int32_t* counts,
+                        int32_t* lvl_list, int32_t* lvl_counts, int max_cand, hipStream_t stream);
+
 // K7. per-image: sort by (conf desc, anchor asc), class-aware greedy NMS (IoU > thr suppresses),
 // keep <= max_det, then scale_boxes to the original frame and clip.
 struct ScaleParams {

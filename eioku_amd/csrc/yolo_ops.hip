@@ -160,6 +160,14 @@ struct DecArgs {
   unsigned long long* keys;  // compact [N][A]
   int32_t* counts;
   const unsigned long long* cm[3];  // class-max words per level (k_decode_cm) or null
+  // lazy box branch (detect()): the box branch's last 1x1 conv runs only for anchors that passed the threshold
+  int32_t* lvl_list;    // [N][A]: level l's passing anchors (level-local index) at [n][A0[l] + k]
+  int32_t* lvl_counts;  // [N][3]
+  float* box_w[3];      // writable alias of box[] (sparse rows filled by k_box_gather)
+  const __half* bin[3]; // input of the box conv per level, fp16 [N][H][W][bin_cs]
+  const uint4* bwgt[3]; // packed 1x1 weights [nchunks][64][4 units]
+  const float* bbias[3];
+  int bin_cs, bnchunks;
 };
 
 __device__ __forceinline__ float dfl_side(const float* __restrict__ l) {
@@ -293,6 +301,122 @@ __global__ __launch_bounds__(256) void k_decode_cm(DecArgs a) {
   const int pos = atomicAdd(&a.counts[n], 1);
   a.keys[(size_t)n * a.A + pos] =
       ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)an);
+}
+
+// ---- lazy box branch -----------------------------------------------------------------------------------------
+// phase 1: threshold on the class-max word, compact key per image (as before) + per-(image, level) anchor list
+__global__ __launch_bounds__(256) void k_decode_pass(DecArgs a) {
+  const long long total = (long long)a.N * a.A;
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i / a.A);
+  const int an = (int)(i % a.A);
+  const int lvl = an >= a.A0[2] ? 2 : (an >= a.A0[1] ? 1 : 0);
+  const int loc = an - a.A0[lvl];
+  const size_t pix = (size_t)n * a.H[lvl] * a.W[lvl] + loc;
+  const unsigned long long word = a.cm[lvl][pix];
+  const float best = __uint_as_float((unsigned)(word & 0xFFFFFFFFull));
+  const float conf = 1.0f / (1.0f + expf(-best));
+  if (!(conf > a.conf)) return;
+  const int pos = atomicAdd(&a.counts[n], 1);
+  a.keys[(size_t)n * a.A + pos] =
+      ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)an);
+  const int k = atomicAdd(&a.lvl_counts[n * 3 + lvl], 1);
+  a.lvl_list[(size_t)n * a.A + a.A0[lvl] + k] = loc;
+}
+
+// phase 2: the box branch's last 1x1 conv (cin -> 64, fp32, no activation) for the listed anchors only: a wave
+// gathers 32 anchors' input rows as its B fragments; same MFMA, same k order as the dense k_conv1x1, so the 64
+// logits written (sparsely) into the box map are bit-identical to what the dense conv would have stored there.
+__global__ __launch_bounds__(256) void k_box_gather(DecArgs a) {
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  typedef float float4v __attribute__((ext_vector_type(4)));
+  const int n = blockIdx.y / 3, lvl = blockIdx.y % 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cnt = a.lvl_counts[n * 3 + lvl];
+  const int g0 = (blockIdx.x * 4 + wave) * 32;
+  if (g0 >= cnt) return;
+  const int r = lane & 15, u = lane >> 4;
+  const int32_t* list = a.lvl_list + (size_t)n * a.A + a.A0[lvl];
+  const size_t img = (size_t)n * a.H[lvl] * a.W[lvl];
+  int loc[2];
+  const __half* row[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int k = g0 + m * 16 + r;
+    loc[m] = list[k < cnt ? k : cnt - 1];
+    row[m] = a.bin[lvl] + (img + loc[m]) * a.bin_cs + u * 8;
+  }
+  float4v acc[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+  const uint4* wl = a.bwgt[lvl] + r * 4 + u;  // packed [kc][64 rows][4 units], unswizzled in global memory
+  for (int kc = 0; kc < a.bnchunks; ++kc) {
+    half8 bf[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const uint4 v = *reinterpret_cast<const uint4*>(row[m] + kc * 32);
+      bf[m] = *reinterpret_cast<const half8*>(&v);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint4 w = wl[(kc * 64 + f * 16) * 4];
+      const half8 af = *reinterpret_cast<const half8*>(&w);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[m], acc[m][f], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    if (g0 + m * 16 + r >= cnt) continue;
+    float* o = a.box_w[lvl] + (img + loc[m]) * 64;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const float4 b = *reinterpret_cast<const float4*>(a.bbias[lvl] + f * 16 + u * 4);
+      *reinterpret_cast<float4v*>(o + f * 16 + u * 4) = acc[m][f] + float4v{b.x, b.y, b.z, b.w};
+    }
+  }
+}
+
+// phase 3: DFL decode of the passing anchors (one thread per compact key)
+__global__ __launch_bounds__(256) void k_decode_boxes(DecArgs a) {
+  const int n = blockIdx.y;
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= a.counts[n]) return;
+  const unsigned long long key = a.keys[(size_t)n * a.A + pos];
+  const int an = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+  const float conf = __uint_as_float((unsigned)(key >> 32));
+  const int lvl = an >= a.A0[2] ? 2 : (an >= a.A0[1] ? 1 : 0);
+  const int loc = an - a.A0[lvl];
+  const int W = a.W[lvl], H = a.H[lvl];
+  const size_t pix = (size_t)n * H * W + loc;
+  const int bj = (int)(a.cm[lvl][pix] >> 32);
+  const float* bl = a.box[lvl] + pix * 64;
+  float side[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float l[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(bl + s * 16 + q * 4);
+      l[q * 4] = v.x; l[q * 4 + 1] = v.y; l[q * 4 + 2] = v.z; l[q * 4 + 3] = v.w;
+    }
+    side[s] = dfl_side(l);
+  }
+  const float stride = (float)(8 << lvl);
+  const float ax = (float)(loc % W) + 0.5f, ay = (float)(loc / W) + 0.5f;
+  // dist2bbox(xywh=True): x1y1 = anchor - lt ; x2y2 = anchor + rb ; c = (x1y1+x2y2)/2 ; wh = x2y2-x1y1
+  const float bx1 = ax - side[0], by1 = ay - side[1], bx2 = ax + side[2], by2 = ay + side[3];
+  const float cx = ((bx1 + bx2) / 2.0f) * stride, cy = ((by1 + by2) / 2.0f) * stride;
+  const float w = (bx2 - bx1) * stride, h = (by2 - by1) * stride;
+  // xywh2xyxy inside non_max_suppression
+  const float hw = w / 2.0f, hh = h / 2.0f;
+  Cand c;
+  c.x1 = cx - hw; c.y1 = cy - hh; c.x2 = cx + hw; c.y2 = cy + hh;
+  c.conf = conf; c.cls = bj; c.anchor = an; c.pad = 0;
+  a.cands[(size_t)n * a.A + an] = c;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -455,6 +579,46 @@ int upsample2x_forward(Slice in, Slice out, int N, int H, int W, int C, hipStrea
   if (N == 0) return EIOKU_OK;
   hipLaunchKernelGGL(k_upsample2x, dim3(blocks_for((long long)N * H * W * (C / 8))), dim3(256), 0, stream,
                      in.ptr + in.coff, in.cstride, out.ptr + out.coff, out.cstride, N, H, W, C / 8);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+// Lazy box branch: threshold on the class-max words, box conv for the passing anchors only, DFL decode of those.
+int decode_lazy_forward(float* const box[3], const unsigned long long* const clsmax[3], const LazyBox& lb, int N,
+                        const int Hl[3], const int Wl[3], int nc, float conf_thres, Cand* cands, int32_t* counts,
+                        int32_t* lvl_list, int32_t* lvl_counts, int max_cand, hipStream_t stream) {
+  if (N == 0) return EIOKU_OK;
+  DecArgs a{};
+  int A = 0, amax = 0;
+  for (int l = 0; l < 3; ++l) {
+    a.box[l] = box[l];
+    a.box_w[l] = box[l];
+    a.cls[l] = nullptr;
+    a.cm[l] = clsmax[l];
+    a.H[l] = Hl[l];
+    a.W[l] = Wl[l];
+    a.A0[l] = A;
+    A += Hl[l] * Wl[l];
+    if (Hl[l] * Wl[l] > amax) amax = Hl[l] * Wl[l];
+    a.bin[l] = lb.in[l];
+    a.bwgt[l] = lb.wgt[l];
+    a.bbias[l] = lb.bias[l];
+  }
+  EIOKU_REQUIRE(A == max_cand, "candidate capacity %d != anchors %d", max_cand, A);
+  a.bin_cs = lb.in_cs;
+  a.bnchunks = lb.nchunks;
+  a.N = N;
+  a.nc = nc;
+  a.A = A;
+  a.conf = conf_thres;
+  a.cands = cands;
+  a.keys = reinterpret_cast<unsigned long long*>(cands + (size_t)N * A);
+  a.counts = counts;
+  a.lvl_list = lvl_list;
+  a.lvl_counts = lvl_counts;
+  hipLaunchKernelGGL(k_decode_pass, dim3(blocks_for((long long)N * A)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_box_gather, dim3((unsigned)((amax + 127) / 128), (unsigned)(N * 3)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_decode_boxes, dim3((unsigned)((A + 255) / 256), (unsigned)N), dim3(256), 0, stream, a);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }

@@ -235,6 +235,13 @@ def test_fused_stem_equals_letterbox_then_network(gpu, h, w):
     assert np.array_equal(counts, counts2)
     for i in range(len(counts)):
         assert np.array_equal(dets[i, :counts[i]], dets2[i, :counts[i]])
+    # a threshold that lets a large share of the anchors through: detect() evaluates the box branch's last conv
+    # per passing anchor (gathered rows) and reads {max logit, argmax} words -- still the dense route's bytes
+    dets, counts = det.detect(frames, conf=0.02, max_det=1000)
+    dets2, counts2 = D.postprocess(box, cls, plan, 0.02, 0.7, 1000)
+    assert counts.min() > 20 and np.array_equal(counts, counts2)
+    for i in range(len(counts)):
+        assert np.array_equal(dets[i, :counts[i]], dets2[i, :counts[i]])
     det.close()
 
 
