@@ -296,7 +296,7 @@ def main():
     for i in range(args.steps):
         if profiled(i):
             torch.cuda.synchronize()  # drain the overlapped steps, time this one's kernels alone, drain again
-            _lib.prof_enable(True)
+            _lib.prof_enable(True, tags=[_lib.PROF_CONV if pipe.det is not None else _lib.PROF_SCENE_HSV])
             pipe.step(i, serial=True)
             torch.cuda.synchronize()
             _lib.prof_enable(False)

@@ -168,8 +168,14 @@ def device_info() -> dict:
 PROF_SCENE_SAD, PROF_SCENE_HSV, PROF_CONV, PROF_KNN, PROF_GEMM = 0, 1, 2, 3, 4
 
 
-def prof_enable(on: bool) -> None:
-    check(load().eioku_prof_enable(int(on)), "eioku_prof_enable")
+def prof_enable(on: bool, tags=None) -> None:
+    """hipEvent brackets on/off; ``tags`` (iterable of PROF_* ids) restricts them to those kernels."""
+    flag = int(bool(on))
+    if on and tags is not None:
+        flag = 0
+        for t in tags:
+            flag |= 1 << (int(t) + 1)
+    check(load().eioku_prof_enable(flag), "eioku_prof_enable")
 
 
 def prof_reset() -> None:

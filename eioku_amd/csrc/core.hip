@@ -15,12 +15,13 @@ int g_cus = 0;
 void* g_scratch[kNumSlots] = {};
 size_t g_scratch_bytes[kNumSlots] = {};
 bool g_prof = false;
+unsigned g_prof_mask = ~0u;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events[EIOKU_PROF_NUM_TAGS];
 size_t g_prof_used[EIOKU_PROF_NUM_TAGS] = {};
 }  // namespace
 
 void prof_start(int tag, hipStream_t stream) {
-  if (!g_prof) return;
+  if (!g_prof || !((g_prof_mask >> tag) & 1u)) return;
   auto& pool = g_prof_events[tag];
   if (g_prof_used[tag] == pool.size()) {
     hipEvent_t a, b;
@@ -31,7 +32,7 @@ void prof_start(int tag, hipStream_t stream) {
 }
 
 void prof_stop(int tag, hipStream_t stream) {
-  if (!g_prof) return;
+  if (!g_prof || !((g_prof_mask >> tag) & 1u)) return;
   auto& pool = g_prof_events[tag];
   if (g_prof_used[tag] >= pool.size()) return;
   (void)hipEventRecord(pool[g_prof_used[tag]].second, stream);
@@ -119,7 +120,9 @@ void eioku_shutdown(void) {
 }
 
 int eioku_prof_enable(int on) {
+  // 0: off; 1: every tag; otherwise a mask: bit (tag + 1) enables that tag's brackets only
   g_prof = on != 0;
+  g_prof_mask = on == 1 ? ~0u : ((unsigned)on >> 1);
   return EIOKU_OK;
 }
 

@@ -68,7 +68,7 @@ enum {
   EIOKU_PROF_GEMM = 4,
   EIOKU_PROF_NUM_TAGS = 8
 };
-int eioku_prof_enable(int on);
+int eioku_prof_enable(int on); /* 0 off, 1 all tags, else mask: bit (tag + 1) enables that tag only */
 int eioku_prof_reset(void);
 int eioku_prof_read(int tag, double* total_ms, uint64_t* launches);
 
