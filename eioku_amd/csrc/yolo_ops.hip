@@ -306,11 +306,9 @@ __global__ __launch_bounds__(256) void k_decode_cm(DecArgs a) {
 // ---- lazy box branch -----------------------------------------------------------------------------------------
 // phase 1: threshold on the class-max word, compact key per image (as before) + per-(image, level) anchor list
 __global__ __launch_bounds__(256) void k_decode_pass(DecArgs a) {
-  const long long total = (long long)a.N * a.A;
-  const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= total) return;
-  const int n = (int)(i / a.A);
-  const int an = (int)(i % a.A);
+  const int n = blockIdx.y;  // (image, anchor) from the grid: the 64-bit div/mod of a flat index cost more than the rest
+  const int an = blockIdx.x * 256 + threadIdx.x;
+  if (an >= a.A) return;
   const int lvl = an >= a.A0[2] ? 2 : (an >= a.A0[1] ? 1 : 0);
   const int loc = an - a.A0[lvl];
   const size_t pix = (size_t)n * a.H[lvl] * a.W[lvl] + loc;
@@ -616,7 +614,7 @@ int decode_lazy_forward(float* const box[3], const unsigned long long* const cls
   a.counts = counts;
   a.lvl_list = lvl_list;
   a.lvl_counts = lvl_counts;
-  hipLaunchKernelGGL(k_decode_pass, dim3(blocks_for((long long)N * A)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_decode_pass, dim3((unsigned)((A + 255) / 256), (unsigned)N), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(k_box_gather, dim3((unsigned)((amax + 127) / 128), (unsigned)(N * 3)), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(k_decode_boxes, dim3((unsigned)((A + 255) / 256), (unsigned)N), dim3(256), 0, stream, a);
   EIOKU_LAUNCH_CHECK();

@@ -17,17 +17,28 @@ def is_pair(r):
     m = re.search(r'k_conv3x3_persist<([^>]*)>', r['Kernel_Name'])
     return bool(m) and m.group(1).replace(' ', '').endswith(',true') and m.group(1).count(',') == 4
 pairs_layers = {'model.1.conv', 'model.3.conv'}
-last, i = [], len(rows) - 1
-need = len(tab)
-while need > 0 and i >= 0:
-    last.append(rows[i]); need -= 2 if is_pair(rows[i]) else 1; i -= 1
-last.reverse()
+def take(n_layers):
+    out, i, need = [], len(rows) - 1, n_layers
+    while need > 0 and i >= 0:
+        out.append(rows[i]); need -= 2 if is_pair(rows[i]) else 1; i -= 1
+    out.reverse()
+    return out
+# detect(): the box branch's last 1x1 (model.22.cv2.l.2) is evaluated lazily by k_box_gather, not launched as a conv
+lazy_names = {n for n, *_ in tab if re.search(r'cv2\.\d\.2$', n)}
+last = take(len(tab) - len(lazy_names))
+lazy = bool(last) and ('k_conv3x3_c8' in last[0]['Kernel_Name'])
+if not lazy:
+    last = take(len(tab))
+    lazy_names = set()
 tot_t = tot_b = tot_f = 0
 print(f"{'layer':28s} {'shape':22s} {'kernel':28s} {'grid':>9s} {'us':>7s} {'MB':>7s} {'GB/s':>6s} {'TF/s':>6s}")
 it = iter(last)
 skip = False
 for (name, cout, cin, k, s) in tab:
     lv = level(name); hin = H >> lv; hout = hin // s
+    if name in lazy_names:
+        print(f"{name:28s} {cin:4d}->{cout:4d} k{k}s{s} @{hout:3d} (lazy: k_box_gather evaluates it for the anchors that pass the threshold)")
+        continue
     if skip:  # ran inside the previous row's launch: its bytes are the output only, its time is already counted
         skip = False
         px_out = batch * hout * hout
