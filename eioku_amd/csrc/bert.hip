@@ -13,6 +13,8 @@
 //   k_pool_norm    attention-mask weighted mean over tokens, then x / max(|x|, 1e-12)
 #include "common.h"
 
+#include <cstdlib>
+
 #include <cmath>
 #include <string>
 #include <vector>
@@ -432,6 +434,85 @@ int find(const eioku_bert* m, const std::string& name) {
 
 const float* tp(const eioku_bert* m, const std::string& name) { return m->tensors[find(m, name)].dev; }
 
+// Small-M GEMM (M < 8192: the ingest path's 8 segments = 1024 tokens).  With 32-deep k-chunks a 64x64 tile is a
+// chain of K/32 dependent load -> LDS -> MFMA rounds (12 for K = 384) and a launch is ~100-400 workgroups, so the
+// chain length IS the kernel's duration.  Here a stage is 128 deep: 16 loads in flight per thread, 64 MFMAs per
+// wave between barriers, 3 stages for K = 384; one LDS buffer (64 KB) + register prefetch keeps 2 workgroups/CU.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_f32_s(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                       int M, int N, int K, int kstages) {
+  constexpr int BM = 64, BN = 64, BKS = 128, UPR = BKS / 4;  // units (float4) per staged row
+  constexpr int RA = BM * UPR / 256, RW = BN * UPR / 256;    // 8 + 8 float4 per thread and stage
+  extern __shared__ __attribute__((aligned(16))) float4 sg[];
+  float4* sA = sg;               // [BM][UPR], unit index swizzled with the row
+  float4* sW = sg + BM * UPR;    // [BN][UPR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int half = lane >> 5, l31 = lane & 31;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // staging map: unit = tid & 31, rows (tid >> 5) + 8 * it
+  const int sunit = tid & 31, srow = tid >> 5;
+  const int k0 = blockIdx.z * kstages * BKS;
+  f32x4 ra[RA], rw[RW];
+  auto issue = [&](int st) {
+#pragma unroll
+    for (int it = 0; it < RA; ++it) {
+      int m = m0 + srow + 8 * it;
+      if (m >= M) m = M - 1;
+      ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + k0 + st * BKS + sunit * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < RW; ++it)
+      rw[it] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + srow + 8 * it) * K + k0 + st * BKS + sunit * 4);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < RA; ++it) {
+      const int row = srow + 8 * it;
+      *reinterpret_cast<f32x4*>(&sA[row * UPR + ((sunit & 16) | ((sunit ^ row) & 15))]) = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < RW; ++it) {
+      const int row = srow + 8 * it;
+      *reinterpret_cast<f32x4*>(&sW[row * UPR + ((sunit & 16) | ((sunit ^ row) & 15))]) = rw[it];
+    }
+  };
+  C += (size_t)blockIdx.z * M * ldc;
+  issue(0);
+  for (int st = 0; st < kstages; ++st) {
+    commit();
+    __syncthreads();
+    if (st + 1 < kstages) issue(st + 1);
+    const int arow = wm * 32 + l31, wrow = wn * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < UPR / 2; ++t) {
+      const int u = 2 * t + half;
+      const float4 a = sA[arow * UPR + ((u & 16) | ((u ^ arow) & 15))];
+      const float4 w = sW[wrow * UPR + ((u & 16) | ((u ^ wrow) & 15))];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int n = n0 + wn * 32 + l31;
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (m < M) {
+      float v = acc[r] + bv;
+      if (EPI == 1) v = gelu_erf(v);
+      C[(size_t)m * ldc + n] = v;
+    }
+  }
+}
+
 constexpr int kMaxSplit = 4;
 
 void launch_add_ln(const float* a, int nsplit, const float* abias, const float* r, int T, int H, const float* g,
@@ -448,6 +529,13 @@ void launch_add_ln(const float* a, int nsplit, const float* abias, const float* 
 int pick_splits(int M, int N, int K) {
   if (M >= 8192) return 1;
   const int blocks = ((M + 63) / 64) * (N / 64);
+  if (K % 128 == 0) {  // k_gemm_f32_s: stages of 128; the largest split <= kMaxSplit that divides them evenly
+    const int stages = K / 128;
+    int best = 1;
+    for (int s = 2; s <= kMaxSplit; ++s)
+      if (stages % s == 0 && blocks * best < 2 * num_cus()) best = s;
+    return best;
+  }
   int s = 1;
   while (s < kMaxSplit && blocks * s < 2 * num_cus() && (K / kBK) % (2 * s) == 0) s *= 2;
   return s;
@@ -466,6 +554,18 @@ int gemm(const float* A, int lda, const float* W, const float* bias, float* C, i
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)(N / 128), (unsigned)splits);
     if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
     else hipLaunchKernelGGL((k_gemm_f32<0, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
+  } else if (K % (128 * splits) == 0 && !(getenv("EIOKU_GEMM_S") && atoi(getenv("EIOKU_GEMM_S")) == 0)) {
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)(N / 64), (unsigned)splits);
+    const size_t lds = (size_t)(64 + 64) * 128 * 4;
+    static bool attr = false;
+    if (!attr) {
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f32_s<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f32_s<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr = true;
+    }
+    const int kstages = K / 128 / splits;
+    if (epi == 1) hipLaunchKernelGGL((k_gemm_f32_s<1>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
+    else hipLaunchKernelGGL((k_gemm_f32_s<0>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
   } else {
     dim3 grid((unsigned)((M + 63) / 64), (unsigned)(N / 64), (unsigned)splits);
     if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1, 64, 64>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
