@@ -17,6 +17,8 @@
 // Algorithmic bytes: N*d*4 per 32-query pass; FLOPs 2*nq*N*d.
 #include "common.h"
 
+#include <cstdlib>
+
 #include <cfloat>
 
 using namespace eioku;
@@ -269,6 +271,208 @@ __global__ __launch_bounds__(256, 1) void k_flat_l2(KnnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide variant on the bf16 matrix pipe (nq > 64).  Exact-fp32 MFMA is 157 TFLOP/s: at 128 queries per database
+// pass the wide kernel above is bound by it (60 % of that peak = 83 ms per 1024 queries over 10 M x 384), not
+// by HBM.  Here every fp32 value is split into two bf16 terms, v = hi + lo + O(2^-17 |v|), and
+//     q . x  ~  q_hi . x_hi  +  q_hi . x_lo  +  q_lo . x_hi          (3 v_mfma_f32_32x32x16_bf16 per 16 dims)
+// accumulated in fp32: 96 matrix-pipe cycles per 16 dims instead of 512.  The dropped lo.lo term and the split
+// remainders are ~2^-16 relative per product, ~1e-6 absolute on the distance of unit vectors: inside the path's
+// 1e-4 tolerance (tests compare against a float64 brute force).  Queries are split once into registers; database
+// rows are split by the staging threads on their way into LDS (hi and lo planes, 16-byte units of 8 dims).
+// Norms stay the fp32 ones.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4k __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2k __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
+  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  hi = (ua >> 16) | (ub & 0xFFFF0000u);  // truncation: the remainder below is then exact in fp32
+  const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);
+  lo = (__float_as_uint(ra) >> 16) | (__float_as_uint(rb) & 0xFFFF0000u);
+}
+
+template <int K, int D>
+__global__ __launch_bounds__(256, 1) void k_flat_l2_bf(KnnArgs a) {
+  constexpr int KC = D < 128 ? D : 128;  // dims per LDS chunk
+  constexpr int NCH = D / KC;
+  constexpr int NS = KC / 16;            // 16-dim MFMA steps per chunk
+  constexpr int PPR = KC / 8;            // 8-dim units per row and plane
+  constexpr int UPR = 2 * PPR;           // units per row: [hi plane | lo plane]
+  constexpr int TILE_U = kRT * UPR;
+  constexpr int SPT = kRT * (KC / 4) / 256;  // staged float4 per thread and chunk
+  constexpr int LISTS = 2, NQ_WG = kQT * kWaves;
+  // a whole row tile (NCH chunks) per buffer, two buffers: the NEXT tile's NCH x 16 KB are in flight (registers)
+  // while this one is multiplied -- with one chunk ahead a CU had 16 KB outstanding and streamed 9 GB/s
+  constexpr size_t STAGE_B = (size_t)2 * NCH * TILE_U * 16 + (size_t)2 * kRT * 4;
+  constexpr size_t MERGE_B = (size_t)NQ_WG * LISTS * K * 8;
+  static_assert(KC % 16 == 0 && D % KC == 0 && (kRT * (KC / 4)) % 256 == 0, "tile shape");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_B > MERGE_B ? STAGE_B : MERGE_B];
+  u32x4k* lds = reinterpret_cast<u32x4k*>(smem);
+  float* lnorm = reinterpret_cast<float*>(smem + (size_t)2 * NCH * TILE_U * 16);  // [2][kRT]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int qt = blockIdx.y * kWaves + wave;
+  const int qi = qt * kQT + col;
+  const bool qvalid = qi < a.nq;
+
+  // query operand of step s: dims 16 s + 8 half + [0, 8), hi and lo terms
+  u32x4k Qh[D / 16], Ql[D / 16];
+  {
+    const float* qp = a.q + (size_t)(qvalid ? qi : 0) * D + 8 * half;
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) {
+      const float4 v0 = *reinterpret_cast<const float4*>(qp + 16 * s);
+      const float4 v1 = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
+      unsigned h[4], l[4];
+      split_bf16x2(v0.x, v0.y, h[0], l[0]);
+      split_bf16x2(v0.z, v0.w, h[1], l[1]);
+      split_bf16x2(v1.x, v1.y, h[2], l[2]);
+      split_bf16x2(v1.z, v1.w, h[3], l[3]);
+      Qh[s] = qvalid ? u32x4k{h[0], h[1], h[2], h[3]} : u32x4k{0, 0, 0, 0};
+      Ql[s] = qvalid ? u32x4k{l[0], l[1], l[2], l[3]} : u32x4k{0, 0, 0, 0};
+    }
+  }
+  const float qn = qvalid ? a.qnorm[qi] : 0.f;
+  TopK<K> top;
+  top.init();
+
+  const long long slab0 = (long long)blockIdx.x * a.rows_per_block;
+  const long long slab1 = min(a.n, slab0 + a.rows_per_block);
+  float4 stage[NCH][SPT];
+  float stage_n = 0.f;
+  auto issue = [&](long long row0) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int it = 0; it < SPT; ++it) {
+        const int id = tid + 256 * it;
+        long long r = row0 + id / (KC / 4);
+        if (r >= slab1) r = slab1 - 1;  // rows past the slab: loaded, multiplied, never inserted
+        stage[ch][it] = *reinterpret_cast<const float4*>(a.db + (size_t)r * D + ch * KC + (id % (KC / 4)) * 4);
+      }
+    long long r = row0 + (tid < kRT ? tid : 0);
+    if (r >= slab1) r = slab1 - 1;
+    stage_n = a.dbnorm[r];
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int it = 0; it < SPT; ++it) {
+        const int id = tid + 256 * it;
+        const int row = id / (KC / 4), fu = id % (KC / 4);  // float4 index inside the row chunk: dims 4 fu .. 4 fu + 3
+        const int p = (fu >> 1) ^ (row & (PPR - 1) & 15), sub = fu & 1;
+        unsigned h0, l0, h1, l1;
+        split_bf16x2(stage[ch][it].x, stage[ch][it].y, h0, l0);
+        split_bf16x2(stage[ch][it].z, stage[ch][it].w, h1, l1);
+        const u32x2k hi = u32x2k{h0, h1}, lo = u32x2k{l0, l1};
+        unsigned char* base = reinterpret_cast<unsigned char*>(lds + (buf * NCH + ch) * TILE_U + row * UPR);
+        *reinterpret_cast<u32x2k*>(base + p * 16 + sub * 8) = hi;
+        *reinterpret_cast<u32x2k*>(base + (PPR + p) * 16 + sub * 8) = lo;
+      }
+    if (tid < kRT) lnorm[buf * kRT + tid] = stage_n;
+  };
+
+  long long row0 = slab0;
+  int buf = 0;
+  if (row0 < slab1) {
+    issue(row0);
+    commit(0);
+  }
+  __syncthreads();
+  while (row0 < slab1) {
+    const long long nrow = row0 + kRT;
+    const bool more = nrow < slab1;
+    if (more) issue(nrow);  // the whole next tile in flight during the MFMAs below
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const u32x4k* rowp = lds + (buf * NCH + ch) * TILE_U + col * UPR;
+      u32x4k xh[NS], xl[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int p = (2 * s + half) ^ (col & (PPR - 1) & 15);
+        xh[s] = rowp[p];
+        xl[s] = rowp[PPR + p];
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const bf16x8 h = __builtin_bit_cast(bf16x8, xh[s]), l = __builtin_bit_cast(bf16x8, xl[s]);
+        const bf16x8 qh = __builtin_bit_cast(bf16x8, Qh[ch * NS + s]), ql = __builtin_bit_cast(bf16x8, Ql[ch * NS + s]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h, qh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l, qh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h, ql, acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const long long row = row0 + lr;
+      if (row < slab1) {
+        float dist = (qn + lnorm[buf * kRT + lr]) - 2.0f * acc[r];
+        dist = dist < 0.f ? 0.f : dist;
+        const int id = (int)(row - slab0);
+        if (top.beats_tail(dist, id)) top.insert(dist, id);
+      }
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    row0 = nrow;
+  }
+
+  // ---- merge the two lists of each query (the two lane halves) inside the workgroup ----
+  __syncthreads();
+  float (*s_mv)[LISTS][K] = reinterpret_cast<float (*)[LISTS][K]>(smem);
+  int (*s_mi)[LISTS][K] = reinterpret_cast<int (*)[LISTS][K]>(smem + (size_t)NQ_WG * LISTS * K * 4);
+  {
+    const int ql = wave * kQT + col;
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+      s_mv[ql][half][p] = top.v[p];
+      s_mi[ql][half][p] = top.id[p];
+    }
+  }
+  __syncthreads();
+  if (tid < NQ_WG) {
+    int head[LISTS] = {0, 0};
+    const int qtile = blockIdx.y * kWaves + tid / kQT;
+    const size_t out = (((size_t)qtile * gridDim.x + blockIdx.x) * kQT + (tid % kQT)) * K;
+    for (int p = 0; p < K; ++p) {
+      float bv = FLT_MAX;
+      int bi = 0x7FFFFFFF, bl = 0;
+#pragma unroll
+      for (int l = 0; l < LISTS; ++l) {
+        if (head[l] < K) {
+          const float v = s_mv[tid][l][head[l]];
+          const int i = s_mi[tid][l][head[l]];
+          if (v < bv || (v == bv && i < bi)) {
+            bv = v;
+            bi = i;
+            bl = l;
+          }
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < LISTS; ++l)
+        if (l == bl) head[l]++;
+      a.pd[out + p] = bv;
+      a.pi[out + p] = bi == 0x7FFFFFFF ? -1 : bi;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_row_norms(const float* x, long long n, int d, float* out) {
   const int lane = threadIdx.x & 63;
   long long row = (blockIdx.x * 256ll + threadIdx.x) >> 6;
@@ -410,6 +614,18 @@ int norms_for(const float* x, long long n, int d, float* out, hipStream_t stream
   const long long cap = (long long)num_cus() * 16;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(k_row_norms, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, d, out);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+template <int K>
+int launch_search_bf(int d, const KnnArgs& a, dim3 grid, hipStream_t stream) {
+  switch (d) {
+    case 128: hipLaunchKernelGGL((k_flat_l2_bf<K, 128>), grid, dim3(256), 0, stream, a); break;
+    case 256: hipLaunchKernelGGL((k_flat_l2_bf<K, 256>), grid, dim3(256), 0, stream, a); break;
+    case 384: hipLaunchKernelGGL((k_flat_l2_bf<K, 384>), grid, dim3(256), 0, stream, a); break;
+    default: return -1;
+  }
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }
@@ -590,7 +806,12 @@ int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D,
   a.id_base = 0;
   dim3 grid((unsigned)slabs, (unsigned)ygroups);
   prof_start(EIOKU_PROF_KNN, stream);
-  if (K == 1) rc = wide ? launch_search_k<1, true>(d, a, grid, stream) : launch_search_k<1, false>(d, a, grid, stream);
+  // wide searches (nq > 64) with k <= 16 over d in {128, 256, 384}: split-bf16 kernel (see k_flat_l2_bf)
+  static const bool bf_off = getenv("EIOKU_KNN_BF16") && atoi(getenv("EIOKU_KNN_BF16")) == 0;
+  rc = -1;
+  if (wide && K == 16 && !bf_off) rc = launch_search_bf<16>(d, a, grid, stream);
+  if (rc != -1) {
+  } else if (K == 1) rc = wide ? launch_search_k<1, true>(d, a, grid, stream) : launch_search_k<1, false>(d, a, grid, stream);
   else if (wide) rc = K == 16 ? launch_search_k<16, true>(d, a, grid, stream) : launch_search_k<32, true>(d, a, grid, stream);
   else rc = K == 16 ? launch_search_k<16, false>(d, a, grid, stream) : launch_search_k<32, false>(d, a, grid, stream);
   prof_stop(EIOKU_PROF_KNN, stream);
