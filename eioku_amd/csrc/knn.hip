@@ -341,9 +341,10 @@ __global__ __launch_bounds__(256, 1) void k_flat_l2_bf(KnnArgs a) {
 
   const long long slab0 = (long long)blockIdx.x * a.rows_per_block;
   const long long slab1 = min(a.n, slab0 + a.rows_per_block);
-  float4 stage[NCH][SPT];
-  float stage_n = 0.f;
-  auto issue = [&](long long row0) {
+  // register ring two tiles deep: tile t+2 is requested while tile t is multiplied (2 x NCH x 16 KB in flight per CU)
+  float4 stage[2][NCH][SPT];
+  float stage_n[2] = {0.f, 0.f};
+  auto issue = [&](long long row0, int slot) {
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
@@ -351,13 +352,13 @@ __global__ __launch_bounds__(256, 1) void k_flat_l2_bf(KnnArgs a) {
         const int id = tid + 256 * it;
         long long r = row0 + id / (KC / 4);
         if (r >= slab1) r = slab1 - 1;  // rows past the slab: loaded, multiplied, never inserted
-        stage[ch][it] = *reinterpret_cast<const float4*>(a.db + (size_t)r * D + ch * KC + (id % (KC / 4)) * 4);
+        stage[slot][ch][it] = *reinterpret_cast<const float4*>(a.db + (size_t)r * D + ch * KC + (id % (KC / 4)) * 4);
       }
     long long r = row0 + (tid < kRT ? tid : 0);
     if (r >= slab1) r = slab1 - 1;
-    stage_n = a.dbnorm[r];
+    stage_n[slot] = a.dbnorm[r];
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, int slot) {
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
@@ -366,27 +367,16 @@ __global__ __launch_bounds__(256, 1) void k_flat_l2_bf(KnnArgs a) {
         const int row = id / (KC / 4), fu = id % (KC / 4);  // float4 index inside the row chunk: dims 4 fu .. 4 fu + 3
         const int p = (fu >> 1) ^ (row & (PPR - 1) & 15), sub = fu & 1;
         unsigned h0, l0, h1, l1;
-        split_bf16x2(stage[ch][it].x, stage[ch][it].y, h0, l0);
-        split_bf16x2(stage[ch][it].z, stage[ch][it].w, h1, l1);
+        split_bf16x2(stage[slot][ch][it].x, stage[slot][ch][it].y, h0, l0);
+        split_bf16x2(stage[slot][ch][it].z, stage[slot][ch][it].w, h1, l1);
         const u32x2k hi = u32x2k{h0, h1}, lo = u32x2k{l0, l1};
         unsigned char* base = reinterpret_cast<unsigned char*>(lds + (buf * NCH + ch) * TILE_U + row * UPR);
         *reinterpret_cast<u32x2k*>(base + p * 16 + sub * 8) = hi;
         *reinterpret_cast<u32x2k*>(base + (PPR + p) * 16 + sub * 8) = lo;
       }
-    if (tid < kRT) lnorm[buf * kRT + tid] = stage_n;
+    if (tid < kRT) lnorm[buf * kRT + tid] = stage_n[slot];
   };
-
-  long long row0 = slab0;
-  int buf = 0;
-  if (row0 < slab1) {
-    issue(row0);
-    commit(0);
-  }
-  __syncthreads();
-  while (row0 < slab1) {
-    const long long nrow = row0 + kRT;
-    const bool more = nrow < slab1;
-    if (more) issue(nrow);  // the whole next tile in flight during the MFMAs below
+  auto multiply = [&](long long row0, int buf) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -426,10 +416,27 @@ __global__ __launch_bounds__(256, 1) void k_flat_l2_bf(KnnArgs a) {
         if (top.beats_tail(dist, id)) top.insert(dist, id);
       }
     }
-    if (more) commit(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-    row0 = nrow;
+  };
+
+  // tile t lives in LDS buffer t & 1 and travelled through register slot t & 1
+  long long row0 = slab0;
+  if (row0 < slab1) {
+    issue(row0, 0);
+    issue(row0 + kRT, 1);  // clamped inside the slab when it does not exist
+    commit(0, 0);
+  }
+  __syncthreads();
+  while (row0 < slab1) {
+    // even tile: multiply buffer 0 while tile+2 loads into slot 0; tile+1 (slot 1) is committed to buffer 1
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      if (row0 >= slab1) break;
+      issue(row0 + 2 * kRT, par);
+      multiply(row0, par);
+      commit(par ^ 1, par ^ 1);
+      __syncthreads();
+      row0 += kRT;
+    }
   }
 
   // ---- merge the two lists of each query (the two lane halves) inside the workgroup ----
