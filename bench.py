@@ -169,11 +169,6 @@ def knn_part(args, device, rank, world):
         dist.barrier()
     torch.cuda.synchronize()
     _lib.prof_enable(True)
-    def profiled(i):
-        if args.prof_every < 0:
-            return i == args.steps // 2
-        return args.prof_every > 0 and i % args.prof_every == 0
-
     _lib.prof_reset()
     t0 = time.perf_counter()
     for _ in range(args.knn_iters):
@@ -195,15 +190,23 @@ def knn_part(args, device, rank, world):
     flops = 2.0 * args.knn_nq * (hi - lo) * d
     out = {"metric": f"kNN QPS@top-10 over {args.knn_n}x{d}", "value": args.knn_nq / per, "unit": "queries/s",
            "nq": args.knn_nq, "k": k, "ms_per_search": per * 1e3, "n_total": args.knn_n, "rows_per_gpu": hi - lo,
-           "dtype": "f32", "collective": "none" if world == 1 else "all_gather_into_tensor (RCCL) of nq*k*16 B per rank",
-           "roofline": ({"kernel": "k_flat_l2 (wide: one DB pass per 128 queries)", "bound": "mfma", "unit": "TFLOP/s",
-                         "peak": MFMA_F32_PEAK_TFLOPS, "achieved": flops / kernel_s / 1e12, "frac": flops / kernel_s / 1e12 / MFMA_F32_PEAK_TFLOPS}
-                        if args.knn_nq > 32 else
-                        {"kernel": "k_flat_l2 (narrow)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                         "achieved": alg_bytes / kernel_s / 1e9, "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS})}
+           "dtype": "f32 (split-bf16 products, fp32 accumulate)" if args.knn_nq > 64 else "f32", "collective": "none" if world == 1 else "all_gather_into_tensor (RCCL) of nq*k*16 B per rank",
+           "roofline": None}
+    streamed = float(hi - lo) * d * 4 * ((args.knn_nq + 127) // 128 if args.knn_nq > 64 else passes)
+    if args.knn_nq > 64:
+        # wide split-bf16 kernel: 3 bf16 MFMAs per 16 dims (7.5 ms of matrix pipe per 1024 x 10M search) and one pass
+        # over the fp32 database per 128 queries (123 GB, 15.4 ms at 8 TB/s): HBM is the roofline that binds
+        out["roofline"] = {"kernel": "k_flat_l2_bf (split-bf16 MFMA, one DB pass per 128 queries)", "bound": "hbm",
+                           "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": streamed / kernel_s / 1e9,
+                           "frac": streamed / kernel_s / 1e9 / HBM_PEAK_GBS,
+                           "mfma_bf16_TFLOPs_executed": 3 * flops / kernel_s / 1e12}
+    else:
+        out["roofline"] = {"kernel": "k_flat_l2 (narrow: one DB pass per 32 queries)", "bound": "hbm", "unit": "GB/s",
+                           "peak": HBM_PEAK_GBS, "achieved": alg_bytes / kernel_s / 1e9,
+                           "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS}
     out["roofline"].update({"avg_kernel_ms": kernel_s * 1e3, "algorithmic_flops_per_launch": flops,
                             "algorithmic_bytes_per_32query_pass": float(hi - lo) * d * 4,
-                            "hbm_bytes_streamed_per_launch": float(hi - lo) * d * 4 * ((args.knn_nq + 127) // 128 if args.knn_nq > 32 else 1)})
+                            "hbm_bytes_streamed_per_launch": streamed})
     ix.close()
     del xb
     torch.cuda.empty_cache()
