@@ -513,6 +513,111 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_s(const float* __restrict__
   }
 }
 
+// Split-bf16 twin of k_gemm_f32_s.  The exact-fp32 matrix pipe (157 TFLOP/s, 64 cycles per 32x32x2 step) is what
+// bounds these GEMMs (the 1024-token QKV GEMM is two rounds of 64x64 tiles at full fp32-MFMA rate).  Each operand
+// value is split into two bf16 terms (v = hi + lo + O(2^-17 |v|)) by the staging threads on the way into LDS and
+// a . w ~ a_hi.w_hi + a_lo.w_hi + a_hi.w_lo runs as 3 v_mfma_f32_32x32x16_bf16 per 16 k (96 cycles instead of 512),
+// accumulated in fp32.  Per-product error ~2^-16 relative; the encoder's outputs stay within the path's 1e-4 bar
+// (tests/test_bert_gpu.py, float64 oracle).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
+
+// round-to-nearest-even to bf16, result in the upper 16 bits (finite inputs)
+__device__ __forceinline__ unsigned bf16_rne_bits(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+}
+
+// hi = RNE(v) (so |v - hi| <= 2^-9 |v| and the difference is exact in fp32), lo = RNE(v - hi): v = hi + lo up to
+// 2^-18 |v|, and the dropped lo.lo products are 2^-18 relative as well -- four times tighter than truncation,
+// which left the encoder's output 2.06e-5 off against a 2.0e-5 bar
+__device__ __forceinline__ void split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const unsigned ha = bf16_rne_bits(a), hb = bf16_rne_bits(b);
+  hi = (ha >> 16) | hb;
+  lo = (bf16_rne_bits(a - __uint_as_float(ha)) >> 16) | bf16_rne_bits(b - __uint_as_float(hb));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                      int M, int N, int K, int kstages) {
+  constexpr int BM = 64, BN = 64, BKS = 128;
+  constexpr int PPR = BKS / 8;   // 8-k units per row and plane
+  constexpr int UPR = 2 * PPR;   // [hi plane | lo plane]
+  constexpr int RA = BM * (BKS / 4) / 256, RW = BN * (BKS / 4) / 256;  // float4 per thread and stage
+  extern __shared__ __attribute__((aligned(16))) u32x4b sgb[];
+  u32x4b* sA = sgb;              // [BM][UPR]
+  u32x4b* sW = sgb + BM * UPR;   // [BN][UPR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int half = lane >> 5, l31 = lane & 31;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int sfu = tid & 31, srow = tid >> 5;  // float4 index inside the staged row (k = 4 sfu ..), rows srow + 8 it
+  const int k0 = blockIdx.z * kstages * BKS;
+  f32x4 ra[RA], rw[RW];
+  auto issue = [&](int st) {
+#pragma unroll
+    for (int it = 0; it < RA; ++it) {
+      int m = m0 + srow + 8 * it;
+      if (m >= M) m = M - 1;
+      ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + k0 + st * BKS + sfu * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < RW; ++it)
+      rw[it] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + srow + 8 * it) * K + k0 + st * BKS + sfu * 4);
+  };
+  auto put = [&](u32x4b* base, int row, const f32x4& v) {
+    const int p = (sfu >> 1) ^ (row & 15), sub = sfu & 1;
+    unsigned h0, l0, h1, l1;
+    split_bf16_pair(v[0], v[1], h0, l0);
+    split_bf16_pair(v[2], v[3], h1, l1);
+    unsigned char* b = reinterpret_cast<unsigned char*>(base + row * UPR);
+    *reinterpret_cast<u32x2b*>(b + p * 16 + sub * 8) = u32x2b{h0, h1};
+    *reinterpret_cast<u32x2b*>(b + (PPR + p) * 16 + sub * 8) = u32x2b{l0, l1};
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < RA; ++it) put(sA, srow + 8 * it, ra[it]);
+#pragma unroll
+    for (int it = 0; it < RW; ++it) put(sW, srow + 8 * it, rw[it]);
+  };
+  C += (size_t)blockIdx.z * M * ldc;
+  issue(0);
+  for (int st = 0; st < kstages; ++st) {
+    commit();
+    __syncthreads();
+    if (st + 1 < kstages) issue(st + 1);
+    const int arow = wm * 32 + l31, wrow = wn * 32 + l31;
+    const u32x4b* ap = sA + arow * UPR;
+    const u32x4b* wp = sW + wrow * UPR;
+#pragma unroll
+    for (int s8 = 0; s8 < BKS / 16; ++s8) {
+      const int pa = (2 * s8 + half) ^ (arow & 15), pw = (2 * s8 + half) ^ (wrow & 15);
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, ap[pa]), al = __builtin_bit_cast(bf16x8, ap[PPR + pa]);
+      const bf16x8 wh = __builtin_bit_cast(bf16x8, wp[pw]), wl = __builtin_bit_cast(bf16x8, wp[PPR + pw]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int n = n0 + wn * 32 + l31;
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (m < M) {
+      float v = acc[r] + bv;
+      if (EPI == 1) v = gelu_erf(v);
+      C[(size_t)m * ldc + n] = v;
+    }
+  }
+}
+
 constexpr int kMaxSplit = 4;
 
 void launch_add_ln(const float* a, int nsplit, const float* abias, const float* r, int T, int H, const float* g,
@@ -550,7 +655,9 @@ int gemm(const float* A, int lda, const float* W, const float* bias, float* C, i
   const int kchunks = K / kBK / splits;
   if (splits > 1) bias = nullptr;
   prof_start(EIOKU_PROF_GEMM, stream);
-  if (M >= 8192) {
+  static const bool bf_all = !(getenv("EIOKU_GEMM_BF16") && atoi(getenv("EIOKU_GEMM_BF16")) == 0) &&
+                             !(getenv("EIOKU_GEMM_BF16_LARGE") && atoi(getenv("EIOKU_GEMM_BF16_LARGE")) == 0);
+  if (M >= 8192 && !(bf_all && K % (128 * splits) == 0)) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)(N / 128), (unsigned)splits);
     if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
     else hipLaunchKernelGGL((k_gemm_f32<0, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
@@ -564,7 +671,16 @@ int gemm(const float* A, int lda, const float* W, const float* bias, float* C, i
       attr = true;
     }
     const int kstages = K / 128 / splits;
-    if (epi == 1) hipLaunchKernelGGL((k_gemm_f32_s<1>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
+    static const bool bf = !(getenv("EIOKU_GEMM_BF16") && atoi(getenv("EIOKU_GEMM_BF16")) == 0);
+    static bool attr2 = false;
+    if (bf && !attr2) {
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr2 = true;
+    }
+    if (bf && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
+    else if (bf) hipLaunchKernelGGL((k_gemm_bf_s<0>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
+    else if (epi == 1) hipLaunchKernelGGL((k_gemm_f32_s<1>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
     else hipLaunchKernelGGL((k_gemm_f32_s<0>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
   } else {
     dim3 grid((unsigned)((M + 63) / 64), (unsigned)(N / 64), (unsigned)splits);
