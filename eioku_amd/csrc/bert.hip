@@ -254,6 +254,108 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
 // attention: grid (B, heads), PARTS lanes per query (each owns the keys j = part mod PARTS), block =
 // PARTS*S threads rounded to 64, head_dim == 32.  qkv: [B*S][3H] = Q | K | V; ctx: [B*S][H]
 // ---------------------------------------------------------------------------------------------
+// S <= 256: 8 lanes per query (keys j = lane, lane + 8, ...), 32 queries per workgroup.  Each lane keeps its <= 32
+// scores in registers (the old kernel computed every score twice: once for the max, once for the exponent) and
+// the K / V rows are swizzled by row so that the 8 rows a query group reads at once hit 8 different bank groups.
+__global__ __launch_bounds__(256) void k_attention8(const float* __restrict__ qkv, const uint8_t* __restrict__ mask, int S,
+                                                    int H, float* __restrict__ ctx) {
+  extern __shared__ __attribute__((aligned(16))) float sm8[];
+  float4* sK = reinterpret_cast<float4*>(sm8);               // [S][8], unit u of row j at j*8 + (u ^ (j & 7))
+  float4* sV = sK + (size_t)S * 8;
+  float* sM = reinterpret_cast<float*>(sV + (size_t)S * 8);  // [S] 1/0
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const size_t row0 = (size_t)b * S;
+  for (int i0 = 0; i0 < S * 8; i0 += 4 * 256) {
+    f32x4 kk[4], vv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int i = i0 + t * 256 + tid;
+      if (i >= S * 8) i = S * 8 - 1;
+      const float* base = qkv + (row0 + (i >> 3)) * (size_t)(3 * H) + h * 32 + (i & 7) * 4;
+      kk[t] = *reinterpret_cast<const f32x4*>(base + H);
+      vv[t] = *reinterpret_cast<const f32x4*>(base + 2 * H);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = i0 + t * 256 + tid;
+      if (i < S * 8) {
+        const int j = i >> 3, u = (i & 7) ^ (j & 7);
+        *reinterpret_cast<f32x4*>(&sK[j * 8 + u]) = kk[t];
+        *reinterpret_cast<f32x4*>(&sV[j * 8 + u]) = vv[t];
+      }
+    }
+  }
+  for (int j = tid; j < S; j += 256) sM[j] = mask[row0 + j] ? 1.f : 0.f;
+  __syncthreads();
+  const int qi = blockIdx.z * 32 + (tid >> 3), part = tid & 7;
+  const bool live = qi < S;
+  float q[32];
+  {
+    const float* qp = qkv + (row0 + (live ? qi : 0)) * (size_t)(3 * H) + h * 32;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(qp + u * 4);
+      q[u * 4] = v[0]; q[u * 4 + 1] = v[1]; q[u * 4 + 2] = v[2]; q[u * 4 + 3] = v[3];
+    }
+  }
+  const float rinv = 0.17677669529663687f;  // 1 / sqrt(32)
+  constexpr int MAXJ = 32;
+  float sc[MAXJ];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int jj = 0; jj < MAXJ; ++jj) {
+    const int j = part + 8 * jj;
+    sc[jj] = -INFINITY;
+    if (j < S) {  // uniform over the wave for all but the last partial group
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 k = sK[j * 8 + (u ^ (j & 7))];
+        s += q[u * 4] * k.x;
+        s += q[u * 4 + 1] * k.y;
+        s += q[u * 4 + 2] * k.z;
+        s += q[u * 4 + 3] * k.w;
+      }
+      if (sM[j] != 0.f) sc[jj] = s * rinv;
+      mx = fmaxf(mx, sc[jj]);
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  float acc[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+  float l = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < MAXJ; ++jj) {
+    const int j = part + 8 * jj;
+    if (j < S && sc[jj] != -INFINITY) {
+      const float e = expf(sc[jj] - mx);
+      l += e;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 v = sV[j * 8 + (u ^ (j & 7))];
+        acc[u * 4] += e * v.x;
+        acc[u * 4 + 1] += e * v.y;
+        acc[u * 4 + 2] += e * v.z;
+        acc[u * 4 + 3] += e * v.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    l += __shfl_xor(l, off, 64);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
+  }
+  if (!live || part != 0) return;
+  float* op = ctx + (row0 + qi) * (size_t)H + h * 32;
+  const float rl = l > 0.f ? 1.0f / l : 0.f;  // fully masked segment -> zeros (its pooled vector is 0 anyway)
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    *reinterpret_cast<f32x4*>(op + u * 4) = f32x4{acc[u * 4] * rl, acc[u * 4 + 1] * rl, acc[u * 4 + 2] * rl, acc[u * 4 + 3] * rl};
+}
+
 template <int PARTS>
 __global__ __launch_bounds__(1024) void k_attention(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                     int S, int H, float* __restrict__ ctx) {
@@ -355,16 +457,17 @@ __global__ __launch_bounds__(1024) void k_pool_norm(const float* __restrict__ x,
   const int b = blockIdx.x, c = threadIdx.x;
   float s = 0.f, cnt = 0.f;
   const int cc = c < H ? c : H - 1;  // loads stay unconditional: 8 tokens in flight per thread, summed in token order
-  for (int t0 = 0; t0 < S; t0 += 8) {
-    float xv[8], mv[8];
+  constexpr int PB = 32;  // tokens in flight per thread: the loop is a chain of S / PB memory round trips
+  for (int t0 = 0; t0 < S; t0 += PB) {
+    float xv[PB], mv[PB];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < PB; ++i) {
       const int t = t0 + i < S ? t0 + i : S - 1;
       mv[i] = (t0 + i < S && mask[(size_t)b * S + t]) ? 1.f : 0.f;
       xv[i] = x[((size_t)b * S + t) * H + cc];
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < PB; ++i) {
       cnt += mv[i];
       s += xv[i] * mv[i];
     }
@@ -856,7 +959,7 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
     if ((rc = gemm(m->x, H, tp(m, p + "attention.self.query.weight"), tp(m, p + "attention.self.query.bias"), m->qkv,
                    3 * H, T, 3 * H, H, 0, 1, stream))) return rc;
     if (parts == 4)
-      hipLaunchKernelGGL(k_attention<4>, dim3(B, m->heads, qsplit), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
+      hipLaunchKernelGGL(k_attention8, dim3(B, m->heads, qsplit), dim3(256), alds, stream, m->qkv, d_mask, S, H, m->ctx);
     else
       hipLaunchKernelGGL(k_attention<1>, dim3(B, m->heads), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
     EIOKU_LAUNCH_CHECK();
