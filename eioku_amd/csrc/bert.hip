@@ -453,35 +453,48 @@ __global__ __launch_bounds__(1024) void k_attention(const float* __restrict__ qk
 // mean pooling (mask weighted) + L2 normalise; one block (H threads) per segment
 __global__ __launch_bounds__(1024) void k_pool_norm(const float* __restrict__ x, const uint8_t* __restrict__ mask,
                                                     int S, int H, float* __restrict__ out) {
+  // blockDim.x = G * Hp (Hp = H rounded up to 64, G = 1 or 2 token groups): group g sums tokens g, g + G, ...
+  // with 32 loads in flight per thread; the mask row sits in LDS (it used to be re-loaded by every thread)
   __shared__ float red[16];
-  const int b = blockIdx.x, c = threadIdx.x;
-  float s = 0.f, cnt = 0.f;
-  const int cc = c < H ? c : H - 1;  // loads stay unconditional: 8 tokens in flight per thread, summed in token order
-  constexpr int PB = 32;  // tokens in flight per thread: the loop is a chain of S / PB memory round trips
-  for (int t0 = 0; t0 < S; t0 += PB) {
-    float xv[PB], mv[PB];
+  __shared__ float smask[1024];
+  __shared__ float psum[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Hp = (H + 63) & ~63, G = blockDim.x / Hp;
+  const int c = tid % Hp, g = tid / Hp;
+  for (int t = tid; t < S; t += blockDim.x) smask[t] = mask[(size_t)b * S + t] ? 1.f : 0.f;
+  __syncthreads();
+  float s = 0.f;
+  const int cc = c < H ? c : H - 1;
+  constexpr int PB = 32;
+  for (int t0 = g; t0 < S; t0 += PB * G) {
+    float xv[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      const int t = t0 + i < S ? t0 + i : S - 1;
-      mv[i] = (t0 + i < S && mask[(size_t)b * S + t]) ? 1.f : 0.f;
+      const int t = t0 + i * G < S ? t0 + i * G : S - 1;
       xv[i] = x[((size_t)b * S + t) * H + cc];
     }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      cnt += mv[i];
-      s += xv[i] * mv[i];
-    }
+    for (int i = 0; i < PB; ++i)
+      if (t0 + i * G < S) s += xv[i] * smask[t0 + i * G];
   }
-  const float v = c < H ? s / fmaxf(cnt, 1e-9f) : 0.f;
-  float sq = v * v;
+  if (g > 0) psum[(g - 1) * Hp + c] = s;
+  __syncthreads();
+  float v = 0.f;
+  if (g == 0) {
+    for (int k = 1; k < G; ++k) s += psum[(k - 1) * Hp + c];  // group order: deterministic
+    float cnt = 0.f;
+    for (int t = 0; t < S; ++t) cnt += smask[t];
+    v = c < H ? s / fmaxf(cnt, 1e-9f) : 0.f;
+  }
+  float sq = v * v;  // zero in the helper groups
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
-  if ((c & 63) == 0) red[c >> 6] = sq;
+  if ((tid & 63) == 0) red[tid >> 6] = sq;
   __syncthreads();
   float tot = 0.f;
   for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
   const float nrm = fmaxf(sqrtf(tot), 1e-12f);
-  if (c < H) out[(size_t)b * H + c] = v / nrm;
+  if (g == 0 && c < H) out[(size_t)b * H + c] = v / nrm;
 }
 
 }  // namespace
@@ -979,7 +992,10 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
     EIOKU_LAUNCH_CHECK();
   }
   const int pthreads = ((H + 63) / 64) * 64;
-  hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(pthreads), 0, stream, m->x, d_mask, S, H, d_out);
+  // two token groups when they fit in a workgroup and in the 1024-float staging arrays
+  const int pgroups = (2 * pthreads <= 1024 && S <= 1024) ? 2 : 1;
+  EIOKU_REQUIRE(S <= 1024, "sequence length %d exceeds the pooling kernel's mask buffer", S);
+  hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(pgroups * pthreads), 0, stream, m->x, d_mask, S, H, d_out);
   EIOKU_LAUNCH_CHECK();
   m->flops_last = (double)T * m->L * (2.0 * H * 3 * H + 2.0 * H * H + 4.0 * H * m->ffn) +
                   (double)B * m->heads * m->L * 4.0 * S * S * 32;
