@@ -524,6 +524,14 @@ struct eioku_bert {
   size_t x_cap = 0, y_cap = 0, qkv_cap = 0, ctx_cap = 0, mid_cap = 0;
   float* d_out = nullptr; size_t out_cap = 0;
   double flops_last = 0;
+  // GEMM weights pre-split into bf16 hi / lo planes (same RNE split the kernel applies on the fly), per layer
+  // [qkv | out | ffn1 | ffn2]; rebuilt lazily after set_tensor
+  struct SplitW {
+    unsigned short* hi = nullptr;
+    unsigned short* lo = nullptr;
+  };
+  std::vector<SplitW> wsplit;  // 4 per layer
+  bool wsplit_dirty = true;
 };
 
 namespace {
@@ -654,8 +662,21 @@ __device__ __forceinline__ void split_bf16_pair(float a, float b, unsigned& hi, 
   lo = (bf16_rne_bits(a - __uint_as_float(ha)) >> 16) | bf16_rne_bits(b - __uint_as_float(hb));
 }
 
-template <int EPI>
+// weights -> bf16 hi / lo planes, once per load: the GEMM then copies 8 + 8 bytes instead of splitting 16
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ w, size_t npairs, unsigned* __restrict__ hi,
+                                                      unsigned* __restrict__ lo) {
+  const size_t i = blockIdx.x * 256ull + threadIdx.x;
+  if (i >= npairs) return;
+  unsigned h, l;
+  split_bf16_pair(w[2 * i], w[2 * i + 1], h, l);
+  hi[i] = h;
+  lo[i] = l;
+}
+
+template <int EPI, bool WS>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                      const unsigned short* __restrict__ Whi,
+                                                      const unsigned short* __restrict__ Wlo,
                                                       const float* __restrict__ bias, float* __restrict__ C, int ldc,
                                                       int M, int N, int K, int kstages) {
   constexpr int BM = 64, BN = 64, BKS = 128;
@@ -674,7 +695,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int sfu = tid & 31, srow = tid >> 5;  // float4 index inside the staged row (k = 4 sfu ..), rows srow + 8 it
   const int k0 = blockIdx.z * kstages * BKS;
-  f32x4 ra[RA], rw[RW];
+  f32x4 ra[RA], rw[WS ? 1 : RW];
+  u32x2b rwh[WS ? RW : 1], rwl[WS ? RW : 1];
   auto issue = [&](int st) {
 #pragma unroll
     for (int it = 0; it < RA; ++it) {
@@ -683,8 +705,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
       ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + k0 + st * BKS + sfu * 4);
     }
 #pragma unroll
-    for (int it = 0; it < RW; ++it)
-      rw[it] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + srow + 8 * it) * K + k0 + st * BKS + sfu * 4);
+    for (int it = 0; it < RW; ++it) {
+      const size_t e = (size_t)(n0 + srow + 8 * it) * K + k0 + st * BKS + sfu * 4;
+      if (WS) {
+        rwh[it] = *reinterpret_cast<const u32x2b*>(Whi + e);
+        rwl[it] = *reinterpret_cast<const u32x2b*>(Wlo + e);
+      } else {
+        rw[it] = *reinterpret_cast<const f32x4*>(W + e);
+      }
+    }
+  };
+  auto put_split = [&](u32x4b* base, int row, u32x2b h, u32x2b l) {
+    const int p = (sfu >> 1) ^ (row & 15), sub = sfu & 1;
+    unsigned char* b = reinterpret_cast<unsigned char*>(base + row * UPR);
+    *reinterpret_cast<u32x2b*>(b + p * 16 + sub * 8) = h;
+    *reinterpret_cast<u32x2b*>(b + (PPR + p) * 16 + sub * 8) = l;
   };
   auto put = [&](u32x4b* base, int row, const f32x4& v) {
     const int p = (sfu >> 1) ^ (row & 15), sub = sfu & 1;
@@ -699,7 +734,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
 #pragma unroll
     for (int it = 0; it < RA; ++it) put(sA, srow + 8 * it, ra[it]);
 #pragma unroll
-    for (int it = 0; it < RW; ++it) put(sW, srow + 8 * it, rw[it]);
+    for (int it = 0; it < RW; ++it) {
+      if (WS) put_split(sW, srow + 8 * it, rwh[it], rwl[it]);
+      else put(sW, srow + 8 * it, rw[it]);
+    }
   };
   C += (size_t)blockIdx.z * M * ldc;
   issue(0);
@@ -765,7 +803,7 @@ int pick_splits(int M, int N, int K) {
 // C = A . W^T (+ bias, + GELU when epi == 1).  splits > 1: C receives `splits` partial planes [splits][M][ldc]
 // WITHOUT bias (epi must be 0); the consumer adds them up.
 int gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int epi,
-         int splits, hipStream_t stream) {
+         int splits, hipStream_t stream, const eioku_bert::SplitW* ws = nullptr) {
   EIOKU_REQUIRE(N % 128 == 0 && K % kBK == 0, "gemm shape N=%d K=%d must be multiples of 128 / 32", N, K);
   EIOKU_REQUIRE(splits >= 1 && (K / kBK) % splits == 0 && (splits == 1 || epi == 0), "bad split-K %d", splits);
   const int kchunks = K / kBK / splits;
@@ -790,12 +828,18 @@ int gemm(const float* A, int lda, const float* W, const float* bias, float* C, i
     static const bool bf = !(getenv("EIOKU_GEMM_BF16") && atoi(getenv("EIOKU_GEMM_BF16")) == 0);
     static bool attr2 = false;
     if (bf && !attr2) {
-      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr2 = true;
     }
-    if (bf && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
-    else if (bf) hipLaunchKernelGGL((k_gemm_bf_s<0>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
+    const unsigned short* whi = ws ? ws->hi : nullptr;
+    const unsigned short* wlo = ws ? ws->lo : nullptr;
+    if (bf && whi && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, true>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
+    else if (bf && whi) hipLaunchKernelGGL((k_gemm_bf_s<0, true>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
+    else if (bf && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, false>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
+    else if (bf) hipLaunchKernelGGL((k_gemm_bf_s<0, false>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
     else if (epi == 1) hipLaunchKernelGGL((k_gemm_f32_s<1>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
     else hipLaunchKernelGGL((k_gemm_f32_s<0>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
   } else {
@@ -889,6 +933,10 @@ void eioku_bert_destroy(eioku_bert* m) {
     const bool sub = n.find("self.key.") != std::string::npos || n.find("self.value.") != std::string::npos;
     if (!sub && m->tensors[i].dev) (void)hipFree(m->tensors[i].dev);
   }
+  for (auto& w : m->wsplit) {
+    if (w.hi) (void)hipFree(w.hi);
+    if (w.lo) (void)hipFree(w.lo);
+  }
   void* bufs[] = {m->d_ids, m->d_mask, m->x, m->y, m->qkv, m->ctx, m->mid, m->d_out};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -913,6 +961,7 @@ int eioku_bert_set_tensor(eioku_bert* m, int idx, const float* host, size_t nume
   EIOKU_REQUIRE(numel == t.numel(), "%s: expected %zu elements, got %zu", t.name.c_str(), t.numel(), numel);
   EIOKU_HIP_CHECK(hipMemcpy(t.dev, host, numel * sizeof(float), hipMemcpyHostToDevice));
   t.set = true;
+  m->wsplit_dirty = true;
   return EIOKU_OK;
 }
 
@@ -929,6 +978,27 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
   hipStream_t stream = (hipStream_t)stream_;
   const int H = m->H, T = B * S;
   int rc;
+  if (m->wsplit_dirty) {  // (re)build the bf16 hi / lo planes of the four GEMM operands of every layer
+    if (m->wsplit.empty()) m->wsplit.resize((size_t)4 * m->L);
+    for (int l = 0; l < m->L; ++l) {
+      const std::string p = "encoder.layer." + std::to_string(l) + ".";
+      const char* names[4] = {"attention.self.query.weight", "attention.output.dense.weight", "intermediate.dense.weight",
+                              "output.dense.weight"};
+      const size_t numel[4] = {(size_t)3 * H * H, (size_t)H * H, (size_t)m->ffn * H, (size_t)H * m->ffn};
+      for (int k = 0; k < 4; ++k) {
+        auto& w = m->wsplit[(size_t)4 * l + k];
+        if (!w.hi) {
+          EIOKU_HIP_CHECK(hipMalloc((void**)&w.hi, numel[k] * 2));
+          EIOKU_HIP_CHECK(hipMalloc((void**)&w.lo, numel[k] * 2));
+        }
+        const size_t npairs = numel[k] / 2;
+        hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, stream, tp(m, p + names[k]),
+                           npairs, (unsigned*)w.hi, (unsigned*)w.lo);
+      }
+    }
+    EIOKU_LAUNCH_CHECK();
+    m->wsplit_dirty = false;
+  }
   const int32_t* d_ids = ids;
   const uint8_t* d_mask = mask;
   float* d_out = out;
@@ -970,7 +1040,7 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
   for (int l = 0; l < m->L; ++l) {
     const std::string p = "encoder.layer." + std::to_string(l) + ".";
     if ((rc = gemm(m->x, H, tp(m, p + "attention.self.query.weight"), tp(m, p + "attention.self.query.bias"), m->qkv,
-                   3 * H, T, 3 * H, H, 0, 1, stream))) return rc;
+                   3 * H, T, 3 * H, H, 0, 1, stream, &m->wsplit[(size_t)4 * l + 0]))) return rc;
     if (parts == 4)
       hipLaunchKernelGGL(k_attention8, dim3(B, m->heads, qsplit), dim3(256), alds, stream, m->qkv, d_mask, S, H, m->ctx);
     else
@@ -978,15 +1048,15 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
     EIOKU_LAUNCH_CHECK();
     const int sp_o = pick_splits(T, H, H), sp_f = pick_splits(T, H, m->ffn);
     if ((rc = gemm(m->ctx, H, tp(m, p + "attention.output.dense.weight"), tp(m, p + "attention.output.dense.bias"), m->y,
-                   H, T, H, H, 0, sp_o, stream))) return rc;
+                   H, T, H, H, 0, sp_o, stream, &m->wsplit[(size_t)4 * l + 1]))) return rc;
     launch_add_ln(m->y, sp_o, sp_o > 1 ? tp(m, p + "attention.output.dense.bias") : nullptr, m->x, T, H,
                        tp(m, p + "attention.output.LayerNorm.weight"), tp(m, p + "attention.output.LayerNorm.bias"),
                        m->eps, m->x, stream);
     EIOKU_LAUNCH_CHECK();
     if ((rc = gemm(m->x, H, tp(m, p + "intermediate.dense.weight"), tp(m, p + "intermediate.dense.bias"), m->mid, m->ffn,
-                   T, m->ffn, H, 1, 1, stream))) return rc;
+                   T, m->ffn, H, 1, 1, stream, &m->wsplit[(size_t)4 * l + 2]))) return rc;
     if ((rc = gemm(m->mid, m->ffn, tp(m, p + "output.dense.weight"), tp(m, p + "output.dense.bias"), m->y, H, T, H,
-                   m->ffn, 0, sp_f, stream))) return rc;
+                   m->ffn, 0, sp_f, stream, &m->wsplit[(size_t)4 * l + 3]))) return rc;
     launch_add_ln(m->y, sp_f, sp_f > 1 ? tp(m, p + "output.dense.bias") : nullptr, m->x, T, H,
                        tp(m, p + "output.LayerNorm.weight"), tp(m, p + "output.LayerNorm.bias"), m->eps, m->x, stream);
     EIOKU_LAUNCH_CHECK();
