@@ -51,12 +51,19 @@ struct FusedInput {
   int mode;             // LetterboxPlan::mode, 0 or 2
 };
 bool fused_input_ok(const ConvWeights& cw, const FusedInput& f, Slice res, const float* out_f32);
+// `up` (1x1 only): the first c_split input channels are the nearest-2x upsample of `src` (half resolution), read in
+// place at (y/2, x/2); the remaining channels come from `in` as usual (the neck's [up(x) | skip] concats).
+struct UpSource {
+  Slice src;
+  int c_split;
+};
 // `post` (3x3 persistent kernel only, see conv_post_ok): a following 1x1 convolution applied to the tile while it
 // is still on chip; `out` then receives post's output and cw's own output tensor is never written.
 bool conv_post_ok(const ConvWeights& cw, const ConvWeights& post);
 int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out, float* out_f32,
                  Slice res, int act, hipStream_t stream, const FusedInput* fused = nullptr,
-                 const ConvWeights* post = nullptr, int post_act = kActSiLU, unsigned long long* clsmax = nullptr);
+                 const ConvWeights* post = nullptr, int post_act = kActSiLU, unsigned long long* clsmax = nullptr,
+                 const struct UpSource* up = nullptr);
 // `clsmax` (1x1, no activation, one cout tile): instead of the output tensor, per pixel one 64-bit word
 // (argmax channel << 32 | float bits of max_c(conv + bias)); ties go to the lower channel.
 bool conv_clsmax_ok(const ConvWeights& cw, int act);

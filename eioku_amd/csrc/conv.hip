@@ -47,6 +47,10 @@ struct ConvArgs {
   // class-max epilogue (1x1, one cout tile, no activation): per pixel {max_c (conv + bias), argmax} instead of the
   // Cout-wide fp32 row -- what the Detect decode needs from the class branch, 8 bytes instead of 4*nc
   unsigned long long* clsmax;
+  // 1x1 with a nearest-2x-upsampled first operand (neck concats [up(x) | skip]): channels [0, c_split) are read from
+  // the half-resolution tensor in2 at (y/2, x/2) instead of from `in` -- the upsampled tensor is never written
+  const __half* in2;
+  int in2_cs, c_split;
 };
 
 // x / d for 0 <= x < 2^24 (exact int->float) with a precomputed 1.0f/d: one multiply and a +-1 fix-up instead
@@ -171,17 +175,27 @@ __global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
   constexpr int KB = 4;
   const int nkb = (a.nchunks + KB - 1) / KB;
   const bool cin_tail = (a.Cin & 31) != 0;
+  const int HWf = a.H * a.W;
+  const float r_hw = 1.0f / (float)HWf, r_w = 1.0f / (float)a.W;
   auto load_blk = [&](long long grp, int kb, u32x4 (&b)[KB][2]) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       long long p = grp * 32 + m * 16 + r;
       if (p >= npix) p = npix - 1;
       const __half* src = a.in + (size_t)p * a.in_cs + u * 8;
+      const __half* src2 = src;
+      if (a.in2) {  // uniform: pixel (n, y, x) -> (n, y/2, x/2) of the half-resolution source
+        const int pi = (int)p;
+        const int n = fast_div(pi, HWf, r_hw), rem = pi - n * HWf;
+        const int y = fast_div(rem, a.W, r_w), x = rem - y * a.W;
+        src2 = a.in2 + ((size_t)(n * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.in2_cs + u * 8;
+      }
 #pragma unroll
       for (int j = 0; j < KB; ++j) {
         int c = (kb * KB + j) * 32;
         if (c + u * 8 >= a.Cin) c = 0;  // past Cin: any in-range address; zeroed below / never multiplied
-        b[j][m] = *reinterpret_cast<const u32x4*>(src + c);
+        const __half* base = c < a.c_split ? src2 : src;
+        b[j][m] = *reinterpret_cast<const u32x4*>(base + c);
       }
     }
   };
@@ -1324,8 +1338,11 @@ bool fused_input_ok(const ConvWeights& cw, const FusedInput& f, Slice res, const
 
 int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out, float* out_f32,
                  Slice res, int act, hipStream_t stream, const FusedInput* fused, const ConvWeights* post, int post_act,
-                 unsigned long long* clsmax) {
+                 unsigned long long* clsmax, const UpSource* up) {
   EIOKU_REQUIRE(cw.d_w, "conv weights not created");
+  EIOKU_REQUIRE(!up || (cw.ks == 1 && up->src.ptr && up->c_split % 32 == 0 && up->c_split <= cw.cin && H % 2 == 0 &&
+                        W % 2 == 0 && (long long)N * H * W < (1ll << 24) && up->src.cstride % 8 == 0 && up->src.coff % 8 == 0),
+                "this layer cannot read an upsampled operand in place");
   EIOKU_REQUIRE(!clsmax || conv_clsmax_ok(cw, act), "class-max output needs a 1x1 conv with one cout tile and no activation");
   EIOKU_REQUIRE(!post || (post->d_w && conv_post_ok(cw, *post) && !res.ptr && !out_f32 && !fused && out.ptr),
                 "this pair of layers cannot run as one launch");
@@ -1366,6 +1383,9 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
   a.post_cout = post ? post->cout : 0;
   a.post_act = post_act;
   a.clsmax = clsmax;
+  a.in2 = up ? up->src.ptr + up->src.coff : nullptr;
+  a.in2_cs = up ? up->src.cstride : 0;
+  a.c_split = up ? up->c_split : 0;
   prof_start(EIOKU_PROF_CONV, stream);
   int rc = EIOKU_OK;
   bool handled = false;

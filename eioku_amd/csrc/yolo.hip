@@ -42,6 +42,8 @@ struct Op {
   int act = kActSiLU;
   int f32_out = -1;  // index into head outputs (0..5) or -1
   bool sole_consumer = false;  // the NEXT op is the only reader of this op's output buffer (set by build_graph)
+  int up_consumer = -1;        // kUp: index of the 1x1 conv that can read the low-resolution source in place
+  int up_from = -1;            // conv: index of the kUp op whose output slice it reads (then that op is skipped)
 };
 
 }  // namespace
@@ -213,6 +215,27 @@ void build_graph(eioku_yolo* y) {
   }
   y->weights.resize(y->names.size());
   y->set.assign(y->names.size(), false);
+  // upsample -> concat -> 1x1: the conv reads the half-resolution source itself when it is the only reader of
+  // the upsampled slice (which sits at channel 0 of the concat buffer)
+  for (size_t i = 0; i < y->ops.size(); ++i) {
+    Op& up = y->ops[i];
+    if (up.kind != kUp || up.out_off != 0) continue;
+    int readers = 0, consumer = -1;
+    for (size_t j = 0; j < y->ops.size(); ++j) {
+      const Op& o = y->ops[j];
+      if (o.in_buf == up.out_buf && o.in_off < up.in_ch) {
+        ++readers;
+        consumer = (int)j;
+      }
+      if (o.res_buf == up.out_buf) readers += 2;
+    }
+    if (readers != 1 || consumer < (int)i) continue;
+    Op& c = y->ops[consumer];
+    if (c.kind == kConv && y->shapes[c.conv][2] == 1 && c.in_off == 0 && c.in_ch >= up.in_ch && up.in_ch % 32 == 0) {
+      up.up_consumer = consumer;
+      c.up_from = (int)i;
+    }
+  }
   // an op whose whole output buffer is read by the next op and by nothing else may hand its tile over on chip
   for (size_t i = 0; i + 1 < y->ops.size(); ++i) {
     Op& op = y->ops[i];
@@ -332,6 +355,15 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
         continue;
       }
       if (lazybox && op.f32_out >= 0 && op.f32_out < 3) continue;  // box branch's last conv: evaluated by decode, per anchor
+      static const bool up_off = getenv("EIOKU_UP_FUSE") && atoi(getenv("EIOKU_UP_FUSE")) == 0;
+      if (op.up_from >= 0 && !up_off && (long long)n * H * W < (1ll << 24)) {
+        const Op& uo = y->ops[op.up_from];
+        UpSource us{Slice{y->bufs[uo.in_buf].ptr, y->bufs[uo.in_buf].ch, uo.in_off}, uo.in_ch};
+        rc = conv_forward(cw, in, n, H, W, out, f32, res, op.act, stream, nullptr, nullptr, kActSiLU, nullptr, &us);
+        flops += cw.flops_per_pixel() * n * conv_out_dim(H, cw.ks, cw.stride) * conv_out_dim(W, cw.ks, cw.stride);
+        if (rc) return rc;
+        continue;
+      }
       if (clsmax && op.f32_out >= 3 && conv_clsmax_ok(cw, op.act))  // class branch: max / argmax words, no logit map
         rc = conv_forward(cw, in, n, H, W, Slice{}, nullptr, Slice{}, op.act, stream, nullptr, nullptr, kActNone,
                           y->clsmax[op.f32_out - 3]);
@@ -361,6 +393,9 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
       }
     } else {
       const Buf& ob = y->bufs[op.out_buf];
+      static const bool up_off2 = getenv("EIOKU_UP_FUSE") && atoi(getenv("EIOKU_UP_FUSE")) == 0;
+      // the consumer's pixel count (4x this op's) decides, exactly as in the conv branch above
+      if (op.up_consumer >= 0 && !up_off2 && (long long)n * H * W * 4 < (1ll << 24)) continue;
       rc = upsample2x_forward(in, Slice{ob.ptr, ob.ch, op.out_off}, n, H, W, op.in_ch, stream);
     }
     if (rc) return rc;
