@@ -133,7 +133,7 @@ __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc
 // B fragment (16 pixels x 32 channels = 16 B per lane) straight from HBM, one k-step ahead of the
 // MFMAs, and waves walk the pixel groups grid-stride with no barrier in the loop.
 // ---------------------------------------------------------------------------------------------
-template <int NF>
+template <int NF, bool UP = false>
 __global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wt = reinterpret_cast<uint4*>(smem);  // [nchunks][16*NF][4 units], swizzled per row
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
       if (p >= npix) p = npix - 1;
       const __half* src = a.in + (size_t)p * a.in_cs + u * 8;
       const __half* src2 = src;
-      if (a.in2) {  // uniform: pixel (n, y, x) -> (n, y/2, x/2) of the half-resolution source
+      if (UP) {  // pixel (n, y, x) -> (n, y/2, x/2) of the half-resolution source
         const int pi = (int)p;
         const int n = fast_div(pi, HWf, r_hw), rem = pi - n * HWf;
         const int y = fast_div(rem, a.W, r_w), x = rem - y * a.W;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
       for (int j = 0; j < KB; ++j) {
         int c = (kb * KB + j) * 32;
         if (c + u * 8 >= a.Cin) c = 0;  // past Cin: any in-range address; zeroed below / never multiplied
-        const __half* base = c < a.c_split ? src2 : src;
+        const __half* base = (UP && c < a.c_split) ? src2 : src;
         b[j][m] = *reinterpret_cast<const u32x4*>(base + c);
       }
     }
@@ -1203,12 +1203,12 @@ int launch_nf(int nf, const ConvArgs& a, int ntiles, hipStream_t stream) {
   return EIOKU_EINVAL;
 }
 
-template <int NF>
-int launch1x1(const ConvArgs& a, int ntiles, hipStream_t stream) {
+template <int NF, bool UP>
+int launch1x1_impl(const ConvArgs& a, int ntiles, hipStream_t stream) {
   const size_t lds = (size_t)a.nchunks * 16 * NF * 64;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
-    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv1x1<NF>),
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv1x1<NF, UP>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = lds;
   }
@@ -1218,9 +1218,14 @@ int launch1x1(const ConvArgs& a, int ntiles, hipStream_t stream) {
   const long long cap = (long long)num_cus() * 8;  // grid-stride beyond ~8 workgroups per CU
   if (bx > cap) bx = cap;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL((k_conv1x1<NF>), dim3((unsigned)bx, (unsigned)ntiles), dim3(256), lds, stream, a, npix);
+  hipLaunchKernelGGL((k_conv1x1<NF, UP>), dim3((unsigned)bx, (unsigned)ntiles), dim3(256), lds, stream, a, npix);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
+}
+
+template <int NF>
+int launch1x1(const ConvArgs& a, int ntiles, hipStream_t stream) {
+  return a.in2 ? launch1x1_impl<NF, true>(a, ntiles, stream) : launch1x1_impl<NF, false>(a, ntiles, stream);
 }
 
 int launch1x1_nf(int nf, const ConvArgs& a, int ntiles, hipStream_t stream) {
