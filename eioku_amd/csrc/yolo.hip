@@ -66,6 +66,13 @@ struct eioku_yolo {
   size_t clsmax_cap[3] = {};
   int32_t* lvl = nullptr;  // lazy box branch: [N][A] per-level lists of passing anchors, then [N][3] counts
   size_t lvl_cap = 0;
+  // deep lazy box branch: flat pixel lists [N*A] (anchors) + [9*N*A] (their neighbourhoods) + 6 counters, and the
+  // share of anchors that passed in the last finished call (pinned host copy, written by the GPU, read without a
+  // sync: it only steers lazy vs dense evaluation of the branch's 3x3 layers -- both give the same bytes)
+  int32_t* flat = nullptr;
+  size_t flat_cap = 0;
+  int32_t* pass_host = nullptr;  // [4]: cnt1[3], N*A of that call
+  int deep_idx[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};  // op indices of cv2.l.0 / cv2.l.1
   Cand* cands = nullptr;  // dense [N][A] followed by keys [N][A]
   size_t cands_cap = 0;
   int32_t* counts = nullptr;  // [N] cand counts + [N] det counts
@@ -215,6 +222,19 @@ void build_graph(eioku_yolo* y) {
   }
   y->weights.resize(y->names.size());
   y->set.assign(y->names.size(), false);
+  // box branch per level: cv2.l.0 -> cv2.l.1 -> cv2.l.2 (f32_out = l); remember the two 3x3 ops
+  for (size_t i = 0; i < y->ops.size(); ++i) {
+    const Op& o2 = y->ops[i];
+    if (o2.kind != kConv || o2.f32_out < 0 || o2.f32_out >= 3) continue;
+    int i1 = -1, i0 = -1;
+    for (size_t j = 0; j < y->ops.size(); ++j)
+      if (y->ops[j].kind == kConv && y->ops[j].f32_out < 0 && y->ops[j].out_buf == o2.in_buf) i1 = (int)j;
+    if (i1 >= 0)
+      for (size_t j = 0; j < y->ops.size(); ++j)
+        if (y->ops[j].kind == kConv && y->ops[j].f32_out < 0 && y->ops[j].out_buf == y->ops[i1].in_buf) i0 = (int)j;
+    y->deep_idx[o2.f32_out][0] = i0;
+    y->deep_idx[o2.f32_out][1] = i1;
+  }
   // upsample -> concat -> 1x1: the conv reads the half-resolution source itself when it is the only reader of
   // the upsampled slice (which sits at channel 0 of the concat buffer)
   for (size_t i = 0; i < y->ops.size(); ++i) {
@@ -303,15 +323,42 @@ int prepare(eioku_yolo* y, int n, int h, int w) {
   if (rc) return rc;
   rc = ensure(&y->lvl, &y->lvl_cap, ((size_t)n * A + (size_t)n * 3) * sizeof(int32_t));
   if (rc) return rc;
+  rc = ensure(&y->flat, &y->flat_cap, ((size_t)10 * n * A + 16) * sizeof(int32_t));
+  if (rc) return rc;
   y->cur_n = n;
   y->cur_h = h;
   y->cur_w = w;
   return EIOKU_OK;
 }
 
+// total of the per-image candidate counts and the anchor total of this call -> 4 ints, copied to a pinned host
+// word without a sync; the NEXT call reads whatever has arrived (see the deep lazy box branch)
+__global__ void k_pass_record(const int32_t* counts, int n, int total, int32_t* out) {
+  __shared__ int s;
+  if (threadIdx.x == 0) s = 0;
+  __syncthreads();
+  int v = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += counts[i];
+  atomicAdd(&s, v);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = s;
+    out[1] = 0;
+    out[2] = 0;
+    out[3] = total;
+  }
+}
+
+int record_pass_rate(eioku_yolo* y, int n, int A, hipStream_t stream) {
+  int32_t* dev = y->flat + (size_t)10 * n * A + 8;
+  hipLaunchKernelGGL(k_pass_record, dim3(1), dim3(256), 0, stream, y->counts, n, n * A, dev);
+  EIOKU_HIP_CHECK(hipMemcpyAsync(y->pass_host, dev, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  return EIOKU_OK;
+}
+
 // part: 0 = every op, 1 = the first op only, 2 = all but the first
 int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedInput* fused, double* flops_out,
-            int part = 0, bool clsmax = false, bool lazybox = false) {
+            int part = 0, bool clsmax = false, bool lazybox = false, bool lazydeep = false) {
   double flops = 0;
   bool skip_next = false;
   int pool_skip = 0;
@@ -355,6 +402,12 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
         continue;
       }
       if (lazybox && op.f32_out >= 0 && op.f32_out < 3) continue;  // box branch's last conv: evaluated by decode, per anchor
+      if (lazydeep) {  // ... and so are its two 3x3 layers
+        const int oi = (int)(&op - &y->ops.front());
+        bool skip = false;
+        for (int l = 0; l < 3; ++l) skip = skip || oi == y->deep_idx[l][0] || oi == y->deep_idx[l][1];
+        if (skip) continue;
+      }
       static const bool up_off = getenv("EIOKU_UP_FUSE") && atoi(getenv("EIOKU_UP_FUSE")) == 0;
       if (op.up_from >= 0 && !up_off && (long long)n * H * W < (1ll << 24)) {
         const Op& uo = y->ops[op.up_from];
@@ -405,7 +458,7 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
 }
 
 int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedInput* fused = nullptr,
-                bool clsmax = false, bool lazybox = false) {
+                bool clsmax = false, bool lazybox = false, bool lazydeep = false) {
   for (size_t i = 0; i < y->set.size(); ++i)
     EIOKU_REQUIRE(y->set[i], "conv %zu (%s) has no weights", i, y->names[i].c_str());
   // opt-in (EIOKU_GRAPH=1): on ROCm 7.2 / MI355X replaying the forward as a graph measured 3.07 ms per bench step
@@ -413,7 +466,7 @@ int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const Fu
   static const bool graphs = getenv("EIOKU_GRAPH") && atoi(getenv("EIOKU_GRAPH")) == 1;
   auto& g = y->net_graph;
   // eager whenever the per-launch event hooks are on (events recorded inside a graph cannot be read back)
-  if (!graphs || prof_enabled() || n == 0 || clsmax) return run_ops(y, n, h, w, stream, fused, &y->conv_flops_last, 0, clsmax, lazybox);
+  if (!graphs || prof_enabled() || n == 0 || clsmax) return run_ops(y, n, h, w, stream, fused, &y->conv_flops_last, 0, clsmax, lazybox, lazydeep);
   // a fused stem reads the CALLER's frames: it stays an ordinary launch so that the graph only ever points at
   // this handle's own buffers and weights
   double flops0 = 0;
@@ -498,6 +551,8 @@ void eioku_yolo_destroy(eioku_yolo* y) {
   for (int i = 0; i < 3; ++i)
     if (y->clsmax[i]) (void)hipFree(y->clsmax[i]);
   if (y->lvl) (void)hipFree(y->lvl);
+  if (y->flat) (void)hipFree(y->flat);
+  if (y->pass_host) (void)hipHostFree(y->pass_host);
   if (y->cands) (void)hipFree(y->cands);
   if (y->counts) (void)hipFree(y->counts);
   if (y->dets) (void)hipFree(y->dets);
@@ -663,7 +718,62 @@ int eioku_yolo_detect(eioku_yolo* y, const uint8_t* bgr, int n, int h, int w, co
       lbx.in_cs = y->bufs[op.in_buf].ch;
       lbx.nchunks = cw.nchunks;
     }
-  rc = run_network(y, n, p.out_h, p.out_w, stream, fuse ? &fi : nullptr, cm, lazy);
+  // Deep: with few anchors passing (the usual case at conf >= 0.25) the branch's two 3x3 layers are evaluated only
+  // where decode needs them.  Which way to go is decided from the previous call's pass rate (<= 3 %): a wrong guess
+  // costs time, never correctness.
+  static const float deep_frac = getenv("EIOKU_LAZY_DEEP_FRAC") ? (float)atof(getenv("EIOKU_LAZY_DEEP_FRAC")) : 0.03f;
+  bool deep = lazy && deep_frac > 0.f;
+  int Hq[3], Wq[3], Aq = 0;
+  for (int l = 0; l < 3; ++l) {
+    Hq[l] = level_dim(p.out_h, 3 + l);
+    Wq[l] = level_dim(p.out_w, 3 + l);
+    Aq += Hq[l] * Wq[l];
+  }
+  if (deep) {
+    if (!y->pass_host) {
+      EIOKU_HIP_CHECK(hipHostMalloc((void**)&y->pass_host, 4 * sizeof(int32_t), hipHostMallocDefault));
+      y->pass_host[0] = y->pass_host[1] = y->pass_host[2] = 0;
+      y->pass_host[3] = 0;  // no history yet -> dense
+    }
+    const volatile int32_t* ph = y->pass_host;
+    const long long passed = (long long)ph[0] + ph[1] + ph[2], total = ph[3];
+    deep = total > 0 && (float)passed <= deep_frac * (float)total;
+    int32_t* f = y->flat;
+    int32_t* fcnt = f + (size_t)10 * n * Aq;
+    size_t off1 = 0, off0 = (size_t)n * Aq;
+    for (int l = 0; l < 3 && deep; ++l) {
+      const int i0 = y->deep_idx[l][0], i1 = y->deep_idx[l][1];
+      if (i0 < 0 || i1 < 0) {
+        deep = false;
+        break;
+      }
+      const Op& o0 = y->ops[i0];
+      const Op& o1 = y->ops[i1];
+      const ConvWeights& w0 = y->weights[o0.conv];
+      const ConvWeights& w1 = y->weights[o1.conv];
+      auto ok3 = [](const ConvWeights& w, const Op& o) {
+        return w.ks == 3 && w.stride == 1 && w.cout == 64 && w.cin % 32 == 0 && o.act == kActSiLU && o.res_buf < 0 && o.f32_out < 0;
+      };
+      if (!ok3(w0, o0) || !ok3(w1, o1) || (long long)n * Hq[l] * Wq[l] >= (1ll << 31)) {
+        deep = false;
+        break;
+      }
+      lbx.c0[l] = LazyConv3{y->bufs[o0.in_buf].ptr + o0.in_off, y->bufs[o0.in_buf].ch, w0.nchunks,
+                            reinterpret_cast<const uint4*>(w0.d_w), 16 * w0.nf, w0.d_b,
+                            y->bufs[o0.out_buf].ptr + o0.out_off, y->bufs[o0.out_buf].ch};
+      lbx.c1[l] = LazyConv3{y->bufs[o1.in_buf].ptr + o1.in_off, y->bufs[o1.in_buf].ch, w1.nchunks,
+                            reinterpret_cast<const uint4*>(w1.d_w), 16 * w1.nf, w1.d_b,
+                            y->bufs[o1.out_buf].ptr + o1.out_off, y->bufs[o1.out_buf].ch};
+      lbx.flat1[l] = f + off1;
+      lbx.flat0[l] = f + off0;
+      off1 += (size_t)n * Hq[l] * Wq[l];
+      off0 += (size_t)9 * n * Hq[l] * Wq[l];
+    }
+    lbx.fcnt = fcnt;
+    lbx.deep = deep;
+  }
+  // the counters are needed (for the next call's decision) whenever the lazy path runs
+  rc = run_network(y, n, p.out_h, p.out_w, stream, fuse ? &fi : nullptr, cm, lazy, deep);
   if (rc) return rc;
 
   int Hl[3], Wl[3], A = 0;
@@ -681,8 +791,10 @@ int eioku_yolo_detect(eioku_yolo* y, const uint8_t* bgr, int n, int h, int w, co
   if (lazy) {
     int32_t* lvl_counts = y->lvl + (size_t)n * A;
     EIOKU_HIP_CHECK(hipMemsetAsync(lvl_counts, 0, (size_t)n * 3 * sizeof(int32_t), stream));
+    if (lbx.deep) EIOKU_HIP_CHECK(hipMemsetAsync(lbx.fcnt, 0, 6 * sizeof(int32_t), stream));
     float* boxw[3] = {y->head[0], y->head[1], y->head[2]};
     rc = decode_lazy_forward(boxw, cmw, lbx, n, Hl, Wl, y->nc, conf, y->cands, y->counts, y->lvl, lvl_counts, A, stream);
+    if (rc == EIOKU_OK && y->pass_host) rc = record_pass_rate(y, n, A, stream);  // history for the next call's choice
   } else {
     rc = decode_forward(box, cm ? nullptr : cls, n, Hl, Wl, y->nc, conf, y->cands, y->counts, A, stream, cm ? cmw : nullptr);
   }

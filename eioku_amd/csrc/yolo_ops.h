@@ -60,11 +60,27 @@ int decode_forward(const float* const box[3], const float* const cls[3], int N, 
 // last 1x1 conv (lb: its fp16 input per level, packed weights with ONE 64-row tile, bias) is evaluated -- into the
 // same rows of box[l] the dense conv would have written -- and decoded.  lvl_list [N][A] / lvl_counts [N][3]
 // (zeroed by the caller) are workspace.
+struct LazyConv3 {  // one 3x3 s1 layer with 64 output channels, bias + SiLU, evaluated at listed pixels
+  const __half* in;
+  int in_cs, nchunks;
+  const uint4* wgt;  // packed [tile][chunk][tap][rows_tile][32]
+  int rows_tile;     // 16 * nf of the packing
+  const float* bias;
+  __half* out;
+  int out_cs;
+};
 struct LazyBox {
   const __half* in[3];
   const uint4* wgt[3];
   const float* bias[3];
   int in_cs, nchunks;
+  // deep = true: the branch's two 3x3 layers are lazy as well (c0 at the 3x3 neighbourhoods of the passing anchors,
+  // c1 at the anchors); flat1 / flat0 [level] are pixel-list workspaces (N*A_l and 9*N*A_l ints), fcnt 6 zeroed ints
+  bool deep = false;
+  LazyConv3 c0[3], c1[3];
+  int32_t* flat1[3];
+  int32_t* flat0[3];
+  int32_t* fcnt;
 };
 int decode_lazy_forward(float* const box[3], const unsigned long long* const clsmax[3], const LazyBox& lb, int N,
                         const int Hl[3], const int Wl[3], int nc, float conf_thres, Cand* cands, int32_t* counts,

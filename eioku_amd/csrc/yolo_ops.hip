@@ -168,6 +168,11 @@ struct DecArgs {
   const uint4* bwgt[3]; // packed 1x1 weights [nchunks][64][4 units]
   const float* bbias[3];
   int bin_cs, bnchunks;
+  // deep lazy box branch: flat per-level pixel lists (global pixel index n*H*W + y*W + x) of the passing anchors
+  // (flat1) and of their in-map 3x3 neighbourhoods (flat0, duplicates allowed), with device-side counts
+  int32_t* flat1[3];
+  int32_t* flat0[3];
+  int32_t* fcnt;  // [6]: cnt1[3], cnt0[3]; nullptr = not requested
 };
 
 __device__ __forceinline__ float dfl_side(const float* __restrict__ l) {
@@ -321,6 +326,19 @@ __global__ __launch_bounds__(256) void k_decode_pass(DecArgs a) {
       ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)an);
   const int k = atomicAdd(&a.lvl_counts[n * 3 + lvl], 1);
   a.lvl_list[(size_t)n * a.A + a.A0[lvl] + k] = loc;
+  if (a.fcnt) {
+    const int W = a.W[lvl], H = a.H[lvl];
+    const int gp = (int)pix, y = loc / W, x = loc - y * W;
+    a.flat1[lvl][atomicAdd(&a.fcnt[lvl], 1)] = gp;
+    int nb[9], c = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx)
+        if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) nb[c++] = gp + dy * W + dx;
+    const int base = atomicAdd(&a.fcnt[3 + lvl], c);
+    for (int i = 0; i < c; ++i) a.flat0[lvl][base + i] = nb[i];
+  }
 }
 
 // phase 2: the box branch's last 1x1 conv (cin -> 64, fp32, no activation) for the listed anchors only: a wave
@@ -581,6 +599,91 @@ int upsample2x_forward(Slice in, Slice out, int N, int H, int W, int C, hipStrea
   return EIOKU_OK;
 }
 
+// A 3x3 stride-1 convolution (Cin = 32*nchunks -> 64, bias + SiLU, fp16 out) evaluated only at the listed pixels:
+// the box branch's two 3x3 layers are needed at the anchors that pass the threshold (layer 1) and at their 3x3
+// neighbourhoods (layer 0), ~1-10 % of the map.  A wave takes 32 listed pixels as its two B fragments and gathers
+// their taps from the dense input; weights come straight from the packed global tile (L2 resident).  Same MFMA,
+// same (chunk outer, tap inner) accumulation order, same epilogue arithmetic as the dense kernels: the fp16 values
+// written at those pixels are the ones the dense launch would have written.
+struct GConv {
+  const __half* in;
+  const uint4* wgt;
+  const float* bias;
+  __half* out;
+  const int32_t* list;
+  const int32_t* count;
+  int H, W, in_cs, out_cs, nchunks, rows_tile;
+};
+struct GArgs {
+  GConv l[3];
+};
+
+__global__ __launch_bounds__(256) void k_conv3x3_gather(GArgs ga) {
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  typedef float float4v __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const GConv& g = ga.l[blockIdx.y];
+  const int cnt = *g.count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int HW = g.H * g.W;
+  for (int g0 = (blockIdx.x * 4 + wave) * 32; g0 < cnt; g0 += gridDim.x * 4 * 32) {
+    int gp[2], py[2], px[2];
+    const __half* base[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int k = g0 + m * 16 + r;
+      gp[m] = g.list[k < cnt ? k : cnt - 1];
+      const int n = gp[m] / HW, rem = gp[m] - n * HW;
+      py[m] = rem / g.W;
+      px[m] = rem - py[m] * g.W;
+      base[m] = g.in + (size_t)gp[m] * g.in_cs + q * 8;
+    }
+    float4v acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < g.nchunks; ++cc) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        half8 bf[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const bool ok = (unsigned)(py[m] + dy) < (unsigned)g.H && (unsigned)(px[m] + dx) < (unsigned)g.W;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(base[m] + (ok ? (dy * g.W + dx) * g.in_cs : 0) + cc * 32);
+          bf[m] = __builtin_bit_cast(half8, ok ? v : u32x4{0, 0, 0, 0});
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int tile = (f * 16) / g.rows_tile, row = f * 16 - tile * g.rows_tile + r;
+          const u32x4 w = *reinterpret_cast<const u32x4*>(
+              g.wgt + ((size_t)(tile * g.nchunks + cc) * 9 + tap) * g.rows_tile * 4 + row * 4 + q);
+          const half8 af = __builtin_bit_cast(half8, w);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[m], acc[m][f], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      if (g0 + m * 16 + r >= cnt) continue;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const float4 b = *reinterpret_cast<const float4*>(g.bias + f * 16 + q * 4);
+        float4v v = acc[m][f] + float4v{b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[j]));  // conv.hip's silu_f32
+        const half4 h = __builtin_convertvector(v, half4);
+        *reinterpret_cast<u32x2*>(g.out + (size_t)gp[m] * g.out_cs + f * 16 + q * 4) = __builtin_bit_cast(u32x2, h);
+      }
+    }
+  }
+}
+
 // Lazy box branch: threshold on the class-max words, box conv for the passing anchors only, DFL decode of those.
 int decode_lazy_forward(float* const box[3], const unsigned long long* const clsmax[3], const LazyBox& lb, int N,
                         const int Hl[3], const int Wl[3], int nc, float conf_thres, Cand* cands, int32_t* counts,
@@ -614,7 +717,27 @@ int decode_lazy_forward(float* const box[3], const unsigned long long* const cls
   a.counts = counts;
   a.lvl_list = lvl_list;
   a.lvl_counts = lvl_counts;
+  a.fcnt = nullptr;
+  if (lb.deep) {
+    a.fcnt = lb.fcnt;
+    for (int l = 0; l < 3; ++l) {
+      a.flat1[l] = lb.flat1[l];
+      a.flat0[l] = lb.flat0[l];
+    }
+  }
   hipLaunchKernelGGL(k_decode_pass, dim3((unsigned)((A + 255) / 256), (unsigned)N), dim3(256), 0, stream, a);
+  if (lb.deep) {
+    // layer 0 at the neighbourhoods, then layer 1 at the anchors; both read / write the dense buffers sparsely
+    GArgs g0, g1;
+    for (int l = 0; l < 3; ++l) {
+      g0.l[l] = GConv{lb.c0[l].in, lb.c0[l].wgt, lb.c0[l].bias, lb.c0[l].out, lb.flat0[l], lb.fcnt + 3 + l, Hl[l], Wl[l],
+                      lb.c0[l].in_cs, lb.c0[l].out_cs, lb.c0[l].nchunks, lb.c0[l].rows_tile};
+      g1.l[l] = GConv{lb.c1[l].in, lb.c1[l].wgt, lb.c1[l].bias, lb.c1[l].out, lb.flat1[l], lb.fcnt + l, Hl[l], Wl[l],
+                      lb.c1[l].in_cs, lb.c1[l].out_cs, lb.c1[l].nchunks, lb.c1[l].rows_tile};
+    }
+    hipLaunchKernelGGL(k_conv3x3_gather, dim3(512, 3), dim3(256), 0, stream, g0);
+    hipLaunchKernelGGL(k_conv3x3_gather, dim3(128, 3), dim3(256), 0, stream, g1);
+  }
   hipLaunchKernelGGL(k_box_gather, dim3((unsigned)((amax + 127) / 128), (unsigned)(N * 3)), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(k_decode_boxes, dim3((unsigned)((A + 255) / 256), (unsigned)N), dim3(256), 0, stream, a);
   EIOKU_LAUNCH_CHECK();
