@@ -313,31 +313,66 @@ __global__ __launch_bounds__(256) void k_decode_cm(DecArgs a) {
 __global__ __launch_bounds__(256) void k_decode_pass(DecArgs a) {
   const int n = blockIdx.y;  // (image, anchor) from the grid: the 64-bit div/mod of a flat index cost more than the rest
   const int an = blockIdx.x * 256 + threadIdx.x;
-  if (an >= a.A) return;
+  const bool valid = an < a.A;
   const int lvl = an >= a.A0[2] ? 2 : (an >= a.A0[1] ? 1 : 0);
   const int loc = an - a.A0[lvl];
-  const size_t pix = (size_t)n * a.H[lvl] * a.W[lvl] + loc;
-  const unsigned long long word = a.cm[lvl][pix];
-  const float best = __uint_as_float((unsigned)(word & 0xFFFFFFFFull));
-  const float conf = 1.0f / (1.0f + expf(-best));
-  if (!(conf > a.conf)) return;
-  const int pos = atomicAdd(&a.counts[n], 1);
-  a.keys[(size_t)n * a.A + pos] =
-      ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)an);
-  const int k = atomicAdd(&a.lvl_counts[n * 3 + lvl], 1);
-  a.lvl_list[(size_t)n * a.A + a.A0[lvl] + k] = loc;
-  if (a.fcnt) {
-    const int W = a.W[lvl], H = a.H[lvl];
-    const int gp = (int)pix, y = loc / W, x = loc - y * W;
-    a.flat1[lvl][atomicAdd(&a.fcnt[lvl], 1)] = gp;
-    int nb[9], c = 0;
+  const int W = a.W[lvl], H = a.H[lvl];
+  const size_t pix = (size_t)n * H * W + (valid ? loc : 0);
+  float conf = 0.f;
+  bool pass = false;
+  if (valid) {
+    const unsigned long long word = a.cm[lvl][pix];
+    const float best = __uint_as_float((unsigned)(word & 0xFFFFFFFFull));
+    conf = 1.0f / (1.0f + expf(-best));
+    pass = conf > a.conf;
+  }
+  if (pass) {
+    const int pos = atomicAdd(&a.counts[n], 1);
+    a.keys[(size_t)n * a.A + pos] =
+        ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)an);
+    const int k = atomicAdd(&a.lvl_counts[n * 3 + lvl], 1);
+    a.lvl_list[(size_t)n * a.A + a.A0[lvl] + k] = loc;
+  }
+  if (!a.fcnt) return;
+  // flat lists for the deep lazy path: ONE atomic per (wave, level, list) reserves the wave's range -- three global
+  // counters taking one atomic per passing anchor serialised the whole kernel (13 -> 93 us)
+  const int lane = threadIdx.x & 63;
+  const int y = loc / W, x = loc - y * W;
+  int nb[9], c = 0;
+  if (pass) {
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
       for (int dx = -1; dx <= 1; ++dx)
-        if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) nb[c++] = gp + dy * W + dx;
-    const int base = atomicAdd(&a.fcnt[3 + lvl], c);
-    for (int i = 0; i < c; ++i) a.flat0[lvl][base + i] = nb[i];
+        if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) nb[c++] = (int)pix + dy * W + dx;
+  }
+  int incl = c;  // inclusive prefix sum of c over the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  for (int l = 0; l < 3; ++l) {
+    const unsigned long long m = __ballot(pass && lvl == l);
+    if (m == 0) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    const int last = 63 - __clzll((long long)m);
+    // the level's lanes are contiguous in a wave (anchors are ordered by level): their neighbour counts are a
+    // contiguous slice of the prefix sums
+    const int before = leader > 0 ? __shfl(incl, leader - 1, 64) : 0;
+    const int total0 = __shfl(incl, last, 64) - before;
+    int base1 = 0, base0 = 0;
+    if (lane == leader) {
+      base1 = atomicAdd(&a.fcnt[l], __popcll(m));
+      base0 = atomicAdd(&a.fcnt[3 + l], total0);
+    }
+    base1 = __shfl(base1, leader, 64);
+    base0 = __shfl(base0, leader, 64);
+    if (pass && lvl == l) {
+      a.flat1[l][base1 + __popcll(m & ((1ull << lane) - 1ull))] = (int)pix;
+      const int o = base0 + (incl - c) - before;
+      for (int i = 0; i < c; ++i) a.flat0[l][o + i] = nb[i];
+    }
   }
 }
 
