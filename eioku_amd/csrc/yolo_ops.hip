@@ -681,25 +681,50 @@ __global__ __launch_bounds__(256) void k_conv3x3_gather(GArgs ga) {
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int f = 0; f < 4; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
-    for (int cc = 0; cc < g.nchunks; ++cc) {
+    // per pixel: which taps fall inside the map (bit t), and their element offsets
+    unsigned okm[2] = {0, 0};
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        half8 bf[2];
+        if ((unsigned)(py[m] + dy) < (unsigned)g.H && (unsigned)(px[m] + dx) < (unsigned)g.W) okm[m] |= 1u << tap;
+      }
+    auto wptr = [&](int cc, int tap, int f) {
+      const int tile = (f * 16) / g.rows_tile, row = f * 16 - tile * g.rows_tile + r;
+      return g.wgt + ((size_t)(tile * g.nchunks + cc) * 9 + tap) * g.rows_tile * 4 + row * 4 + q;
+    };
+    for (int cc = 0; cc < g.nchunks; ++cc) {
+      // the chunk's 18 activation fragments in flight together (one load -> wait -> MFMA per step was a chain of
+      // ~70 dependent L2 round trips per wave), weights one tap ahead
+      u32x4 bv[9][2];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const bool ok = (unsigned)(py[m] + dy) < (unsigned)g.H && (unsigned)(px[m] + dx) < (unsigned)g.W;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(base[m] + (ok ? (dy * g.W + dx) * g.in_cs : 0) + cc * 32);
-          bf[m] = __builtin_bit_cast(half8, ok ? v : u32x4{0, 0, 0, 0});
+          const bool ok = (okm[m] >> tap) & 1u;
+          bv[tap][m] = *reinterpret_cast<const u32x4*>(base[m] + (ok ? (dy * g.W + dx) * g.in_cs : 0) + cc * 32);
+        }
+      }
+      u32x4 aw[2][4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) aw[0][f] = *reinterpret_cast<const u32x4*>(wptr(cc, 0, f));
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) aw[(tap + 1) & 1][f] = *reinterpret_cast<const u32x4*>(wptr(cc, tap + 1, f));
         }
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          const int tile = (f * 16) / g.rows_tile, row = f * 16 - tile * g.rows_tile + r;
-          const u32x4 w = *reinterpret_cast<const u32x4*>(
-              g.wgt + ((size_t)(tile * g.nchunks + cc) * 9 + tap) * g.rows_tile * 4 + row * 4 + q);
-          const half8 af = __builtin_bit_cast(half8, w);
+          const half8 af = __builtin_bit_cast(half8, aw[tap & 1][f]);
 #pragma unroll
-          for (int m = 0; m < 2; ++m) acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[m], acc[m][f], 0, 0, 0);
+          for (int m = 0; m < 2; ++m) {
+            const bool ok = (okm[m] >> tap) & 1u;
+            const half8 bf = __builtin_bit_cast(half8, ok ? bv[tap][m] : u32x4{0, 0, 0, 0});
+            acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[m][f], 0, 0, 0);
+          }
         }
       }
     }
