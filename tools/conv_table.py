@@ -9,7 +9,7 @@ def level(name):
     if i == 22: return 3 + int(name.split('.')[3])
     return {0:0,1:1,2:2,3:2,4:3,5:3,6:4,7:4,8:5,9:5,12:4,15:3,16:3,18:4,19:4,21:5}[i]
 fs = sorted(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)
-rows = [r for r in csv.DictReader(open(fs[-1])) if 'k_conv' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(fs[-1])) if 'k_conv' in r['Kernel_Name'] and 'gather' not in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # a launch whose kernel carries POST = true (5th template argument) also ran the NEXT layer (3x3 + 1x1 pair): walk the
 # trace backwards from its end, one forward's worth of layers
@@ -23,13 +23,15 @@ def take(n_layers):
         out.append(rows[i]); need -= 2 if is_pair(rows[i]) else 1; i -= 1
     out.reverse()
     return out
-# detect(): the box branch's last 1x1 (model.22.cv2.l.2) is evaluated lazily by k_box_gather, not launched as a conv
-lazy_names = {n for n, *_ in tab if re.search(r'cv2\.\d\.2$', n)}
-last = take(len(tab) - len(lazy_names))
-lazy = bool(last) and ('k_conv3x3_c8' in last[0]['Kernel_Name'])
-if not lazy:
-    last = take(len(tab))
-    lazy_names = set()
+# detect(): the box branch's last 1x1 (model.22.cv2.l.2) is evaluated lazily by k_box_gather, and with few anchors
+# passing so are its two 3x3 layers (k_conv3x3_gather): those rows have no conv launch of their own
+lazy_names, last = set(), []
+for pat in (r'cv2\.\d\.[012]', r'cv2\.\d\.2$', None):
+    names = {n for n, *_ in tab if pat and re.search(pat, n)}
+    cand = take(len(tab) - len(names))
+    if cand and ('k_conv3x3_c8' in cand[0]['Kernel_Name'] or pat is None):
+        lazy_names, last = names, cand
+        break
 tot_t = tot_b = tot_f = 0
 print(f"{'layer':28s} {'shape':22s} {'kernel':28s} {'grid':>9s} {'us':>7s} {'MB':>7s} {'GB/s':>6s} {'TF/s':>6s}")
 it = iter(last)
@@ -37,7 +39,7 @@ skip = False
 for (name, cout, cin, k, s) in tab:
     lv = level(name); hin = H >> lv; hout = hin // s
     if name in lazy_names:
-        print(f"{name:28s} {cin:4d}->{cout:4d} k{k}s{s} @{hout:3d} (lazy: k_box_gather evaluates it for the anchors that pass the threshold)")
+        print(f"{name:28s} {cin:4d}->{cout:4d} k{k}s{s} @{hout:3d} (lazy: evaluated only where decode needs it -- k_conv3x3_gather / k_box_gather)")
         continue
     if skip:  # ran inside the previous row's launch: its bytes are the output only, its time is already counted
         skip = False
