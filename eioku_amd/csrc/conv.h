@@ -64,6 +64,11 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
                  Slice res, int act, hipStream_t stream, const FusedInput* fused = nullptr,
                  const ConvWeights* post = nullptr, int post_act = kActSiLU, unsigned long long* clsmax = nullptr,
                  const struct UpSource* up = nullptr);
+// Two chained 3x3 stride-1 layers with 16 / 32 channels (a C2f Bottleneck) as one launch: out = act_b(B(act_a(A(in))))
+// [+ in when `residual`]; the intermediate tensor stays in LDS.  Bit-identical to the two separate launches.
+bool conv_chain_ok(const ConvWeights& a, const ConvWeights& b);
+int conv_chain_forward(const ConvWeights& a, const ConvWeights& b, Slice in, int N, int H, int W, Slice out,
+                       bool residual, int act_a, int act_b, hipStream_t stream);
 // `clsmax` (1x1, no activation, one cout tile): instead of the output tensor, per pixel one 64-bit word
 // (argmax channel << 32 | float bits of max_c(conv + bias)); ties go to the lower channel.
 bool conv_clsmax_ok(const ConvWeights& cw, int act);

@@ -789,6 +789,214 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two chained 3x3 stride-1 convolutions (a C2f Bottleneck: cv1 -> cv2 [+ x]) as ONE persistent launch for the
+// shallow layers (16 / 32 channels at 160^2 / 80^2) that are bound by memory traffic and launch count, not by
+// MFMA: the intermediate tensor lives only in LDS.  Per 8x16 output tile the workgroup stages the 12x20 input
+// halo patch X, evaluates conv A on the 10x18 pixels conv B needs (12 fragments of 16 flattened patch pixels:
+// 1.4x conv A's MFMAs, which are idle anyway), writes act(A) as fp16 into the LDS patch P1 with ZEROS where the
+// pixel lies outside the map (that is conv B's padding), runs conv B out of P1 and adds the residual -- the
+// Bottleneck's own input, i.e. the centre of X -- from LDS.  Values are rounded exactly where the two separate
+// launches round them (fp16 intermediate, fp16(fp16(y) + x) residual), so the result is bit-identical.
+// HBM per pair: 1.9x-halo read + 1 write instead of 2 reads + residual read + 2 writes.
+// ---------------------------------------------------------------------------------------------
+template <int NF, bool DB>
+__global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, int total_tiles) {
+  constexpr int XH = kTH + 4, XW = kTW + 4;  // input patch
+  constexpr int PH = kTH + 2, PW = kTW + 2;  // intermediate patch
+  constexpr int X_U = XH * XW * 4, P_U = PH * PW * 4;
+  constexpr int WT_U = 9 * 16 * NF * 4;
+  constexpr int NLOAD = X_U;
+  constexpr int R = (NLOAD + 255) / 256;
+  constexpr int NPA = PH * PW;           // conv A pixels per tile
+  constexpr int MA = (NPA + 63) / 64;    // conv A fragments per wave
+  static_assert(NF == 1 || NF == 2, "one 32-channel chunk on both convolutions");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* wtA = reinterpret_cast<uint4*>(smem);
+  uint4* wtB = wtA + WT_U;
+  uint4* xbuf = wtB + WT_U;                     // [DB ? 2 : 1][X_U] + 4 spare units
+  uint4* p1 = xbuf + (DB ? 2 : 1) * X_U + 4;    // [P_U] + 4 spare units (stores of the last fragment's tail)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int s_off[R], s_py[R], s_px[R], s_rel[R];
+  unsigned s_live = 0;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int idx = tid + 256 * j;
+    const int pix = idx >> 2, unit = idx & 3;
+    const int py = pix / XW, px = pix - py * XW;
+    const bool in_patch = idx < NLOAD;
+    s_off[j] = in_patch ? pix * 4 + (unit ^ ((pix >> 1) & 3)) : (DB ? 2 : 1) * X_U;
+    s_py[j] = py;
+    s_px[j] = px;
+    s_rel[j] = (py * a.W + px) * a.in_cs + unit * 8;
+    if (in_patch && unit * 8 < a.Cin) s_live |= 1u << j;
+  }
+  const int tiles_per_img = a.tiles_w * a.tiles_h;
+  const float r_tpi = 1.0f / (float)tiles_per_img, r_tw = 1.0f / (float)a.tiles_w;
+  u32x4 stage[R];
+  unsigned s_ok = 0;
+  int nx_n = 0, nx_th = 0, nx_tw = 0;
+  auto issue = [&](int tile) {
+    nx_n = fast_div(tile, tiles_per_img, r_tpi);
+    const int t2 = tile - nx_n * tiles_per_img;
+    nx_th = fast_div(t2, a.tiles_w, r_tw);
+    nx_tw = t2 - nx_th * a.tiles_w;
+    const int ih0 = nx_th * kTH - 2, iw0 = nx_tw * kTW - 2;
+    const int base = ((nx_n * a.H + ih0) * a.W + iw0) * a.in_cs;
+    s_ok = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int ih = ih0 + s_py[j], iw = iw0 + s_px[j];
+      const bool ok = ((s_live >> j) & 1) && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      s_ok |= (ok ? 1u : 0u) << j;
+      stage[j] = *reinterpret_cast<const u32x4*>(a.in + (ok ? base + s_rel[j] : 0));
+    }
+  };
+
+  // conv A: fragment m of this wave = flattened P1 pixels (wave + 4m)*16 .. +15 (clamped: the last fragment's
+  // tail computes pixel NPA-1 again and stores nothing)
+  int bposA[9][MA];
+  int pa_st[MA][NF], pa_y[MA], pa_x[MA];  // pa_st: byte offset in P1 of this lane's 4 channels of fragment (m, f)
+#pragma unroll
+  for (int m = 0; m < MA; ++m) {
+    const int praw = (wave + 4 * m) * 16 + (lane & 15);
+    const int p = praw < NPA ? praw : NPA - 1;
+    const int py = p / PW, px = p - py * PW;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int unit = f * 2 + (lane >> 5), half = (lane >> 4) & 1;
+      pa_st[m][f] = (praw < NPA ? p * 4 + (unit ^ ((p >> 1) & 3)) : P_U + unit) * 16 + half * 8;
+    }
+    pa_y[m] = py;
+    pa_x[m] = px;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int pos = (py + tap / 3) * XW + px + tap % 3;
+      bposA[tap][m] = pos * 4 + ((lane >> 4) ^ ((pos >> 1) & 3));
+    }
+  }
+  int bposB[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int p = (wave * 2 + m + tap / 3) * PW + (lane & 15) + tap % 3;
+      bposB[tap][m] = p * 4 + ((lane >> 4) ^ ((p >> 1) & 3));
+    }
+  const int wsel = (lane & 15) * 4 + ((lane >> 4) ^ ((lane >> 1) & 3));
+  const uint4* wtA_lane = wtA + wsel;
+  const uint4* wtB_lane = wtB + wsel;
+  float4 biasA[NF], biasB[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    biasA[f] = *reinterpret_cast<const float4*>(a.bias + f * 16 + (lane >> 4) * 4);
+    biasB[f] = *reinterpret_cast<const float4*>(a.post_bias + f * 16 + (lane >> 4) * 4);
+  }
+
+  int tile = blockIdx.x;
+  if (tile < total_tiles) issue(tile);
+  {
+    constexpr int NW = 2 * WT_U, WB = 8;
+    for (int i0 = 0; i0 < NW; i0 += 256 * WB) {
+      u32x4 w[WB];
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int idx = i0 + j * 256 + tid;
+        const int k = idx < NW ? idx : 0;
+        w[j] = *reinterpret_cast<const u32x4*>(k < WT_U ? a.wgt + k : a.post_w + (k - WT_U));
+      }
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int idx = i0 + j * 256 + tid;
+        const int row = (idx % WT_U) >> 2, unit = idx & 3;
+        if (idx < NW) *reinterpret_cast<u32x4*>(wtA + (idx & ~3) + (unit ^ ((row >> 1) & 3))) = w[j];
+      }
+    }
+    // channels 16*NF..31 of P1 are never written: they must read as zero, not as whatever LDS held
+    for (int i = tid; i < P_U; i += 256) *reinterpret_cast<u32x4*>(p1 + i) = u32x4{0, 0, 0, 0};
+  }
+  int buf = 0;
+  for (; tile < total_tiles; tile += gridDim.x) {
+    uint4* xb = xbuf + (DB ? buf : 0) * X_U;
+    if (!DB) __syncthreads();  // every wave is done with the previous tile's X (residual) and P1
+    if (s_ok != s_live) {
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        if (!((s_ok >> j) & 1)) stage[j] = u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) *reinterpret_cast<u32x4*>(xb + s_off[j]) = stage[j];
+    __syncthreads();
+    const int tn = nx_n, tth = nx_th, ttw = nx_tw;
+    const int next = tile + gridDim.x;
+    if (next < total_tiles) issue(next);
+    __builtin_amdgcn_sched_barrier(0);
+
+    {
+      float4v acc[MA][NF];
+#pragma unroll
+      for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+      mma_taps<NF, MA>(xb, wtA_lane, bposA, acc);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MA; ++m) {
+        const int ah = tth * kTH - 1 + pa_y[m], aw = ttw * kTW - 1 + pa_x[m];
+        const bool inmap = (unsigned)ah < (unsigned)a.H && (unsigned)aw < (unsigned)a.W;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const float4v v = activate_frag(a, acc[m][f], biasA[f]);
+          const f16x4 h = __builtin_convertvector(v, f16x4);
+          const u32x2 hv = inmap ? __builtin_bit_cast(u32x2, h) : u32x2{0, 0};
+          *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p1) + pa_st[m][f]) = hv;
+        }
+      }
+    }
+    __syncthreads();
+
+    float4v acc[2][NF];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+    mma_taps<NF, 2>(p1, wtB_lane, bposB, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    const int ow = ttw * kTW + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int oh = tth * kTH + wave * 2 + m;
+      const int pos = (2 + wave * 2 + m) * XW + 2 + (lane & 15);
+      u32x2 resv[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int unit = f * 2 + (lane >> 5), half = (lane >> 4) & 1;
+        resv[f] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(xb + pos * 4 + (unit ^ ((pos >> 1) & 3))) + half * 8);
+      }
+      if (oh >= a.Ho || ow >= a.Wo) continue;
+      const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        // Cout = 16*NF exactly: always the full-vector store of store_frag, same roundings
+        float4v v = acc[m][f] + float4v{biasB[f].x, biasB[f].y, biasB[f].z, biasB[f].w};
+        if (a.post_act == kActSiLU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = silu_f32(v[j]);
+        }
+        f16x4 h = __builtin_convertvector(v, f16x4);
+        if (a.res) {
+          const float4v sum = __builtin_convertvector(h, float4v) + __builtin_convertvector(__builtin_bit_cast(f16x4, resv[f]), float4v);
+          h = __builtin_convertvector(sum, f16x4);
+        }
+        *reinterpret_cast<u32x2*>(a.post_out + opix * a.post_out_cs + f * 16 + (lane >> 4) * 4) = __builtin_bit_cast(u32x2, h);
+      }
+    }
+    buf ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stem variant (Cin = 8: RGB + 5 zero channels, stride 2).  The generic kernels pad the 8 channels to a
 // 32-channel chunk (3/4 of every MFMA and of every LDS byte is zero); here the K axis of a chunk is
 // 4 TAPS x 8 channels instead: lane group q of a B fragment reads the pixel of tap 4j+q, so the 3x3
@@ -1105,6 +1313,30 @@ int launch_persist_post_dispatch(int nf, int nch, bool db, const ConvArgs& a, hi
   return EIOKU_OK;
 }
 
+size_t chain_lds(int nf, bool db) {
+  return ((size_t)2 * 9 * 16 * nf * 4 + (db ? 2 : 1) * (size_t)(kTH + 4) * (kTW + 4) * 4 + 4 + (size_t)(kTH + 2) * (kTW + 2) * 4 + 4) * 16;
+}
+
+template <int NF, bool DB>
+int launch_chain(const ConvArgs& a, hipStream_t stream) {
+  const size_t lds = chain_lds(NF, DB);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_chain<NF, DB>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int total = a.tiles_w * a.tiles_h * a.N;
+  int per_cu = (int)(150 * 1024 / lds);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 4) per_cu = 4;
+  int bx = num_cus() * per_cu;
+  if (bx > total) bx = total;
+  hipLaunchKernelGGL((k_conv3x3_chain<NF, DB>), dim3((unsigned)bx), dim3(256), lds, stream, a, total);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
 // Flattened-pixel deep-K launch: geometry of the worst-case patch, then the largest tile whose staging
 // fits the per-thread slot budget.  *handled = false leaves the layer to the generic kernel.
 struct FlatGeom {
@@ -1334,6 +1566,57 @@ bool conv_post_ok(const ConvWeights& cw, const ConvWeights& post) {
   if (!shape) return false;
   const size_t extra = ((size_t)((cw.nf + 1) / 2) * 16 * cw.nf * 4 + 4 * 32 * 2 * cw.nf) * 16;
   return persist_lds(cw.nf, cw.stride, cw.nchunks, false) + extra <= 150 * 1024;
+}
+
+bool conv_chain_ok(const ConvWeights& a, const ConvWeights& b) {
+  static const bool off = getenv("EIOKU_CONV_CHAIN") && atoi(getenv("EIOKU_CONV_CHAIN")) == 0;
+  if (off) return false;
+  auto one = [](const ConvWeights& c) {
+    return c.ks == 3 && c.stride == 1 && c.nchunks == 1 && c.ntiles == 1 && (c.nf == 1 || c.nf == 2) && c.cout == 16 * c.nf &&
+           c.cin == c.cout;
+  };
+  return one(a) && one(b) && a.nf == b.nf;
+}
+
+int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, int N, int H, int W, Slice out,
+                       bool residual, int act_a, int act_b, hipStream_t stream) {
+  EIOKU_REQUIRE(ca.d_w && cb.d_w && conv_chain_ok(ca, cb), "this pair of 3x3 layers cannot run as one launch");
+  EIOKU_REQUIRE(in.ptr && out.ptr && in.cstride % 8 == 0 && in.coff % 8 == 0 && out.cstride % 4 == 0 && out.coff % 4 == 0,
+                "bad slices");
+  if (N == 0) return EIOKU_OK;
+  ConvArgs a{};
+  a.in = in.ptr + in.coff;
+  a.wgt = reinterpret_cast<const uint4*>(ca.d_w);
+  a.bias = ca.d_b;
+  a.res = residual ? a.in : nullptr;  // the Bottleneck's shortcut is its own input: read from the staged patch
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.Cin = ca.cin;
+  a.in_cs = in.cstride;
+  a.Ho = H;
+  a.Wo = W;
+  a.Cout = ca.cout;
+  a.res_cs = in.cstride;
+  a.tiles_w = (W + kTW - 1) / kTW;
+  a.tiles_h = (H + kTH - 1) / kTH;
+  a.nchunks = 1;
+  a.act = act_a;
+  a.post_w = reinterpret_cast<const uint4*>(cb.d_w);
+  a.post_bias = cb.d_b;
+  a.post_out = out.ptr + out.coff;
+  a.post_out_cs = out.cstride;
+  a.post_cout = cb.cout;
+  a.post_act = act_b;
+  prof_start(EIOKU_PROF_CONV, stream);
+  static const int db_env = getenv("EIOKU_CHAIN_DB") ? atoi(getenv("EIOKU_CHAIN_DB")) : -1;
+  // double-buffer the input patch while that still leaves two workgroups per CU
+  const bool db = db_env >= 0 ? db_env != 0 : chain_lds(ca.nf, true) <= 75 * 1024;
+  int rc;
+  if (ca.nf == 1) rc = db ? launch_chain<1, true>(a, stream) : launch_chain<1, false>(a, stream);
+  else rc = db ? launch_chain<2, true>(a, stream) : launch_chain<2, false>(a, stream);
+  prof_stop(EIOKU_PROF_CONV, stream);
+  return rc;
 }
 
 bool fused_input_ok(const ConvWeights& cw, const FusedInput& f, Slice res, const float* out_f32) {

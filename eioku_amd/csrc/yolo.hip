@@ -41,6 +41,7 @@ struct Op {
   int res_buf = -1, res_off = 0;
   int act = kActSiLU;
   int f32_out = -1;  // index into head outputs (0..5) or -1
+  bool chain_next = false;     // this op's output is read by the NEXT op only, before anything overwrites it (C2f's shared tmp)
   bool sole_consumer = false;  // the NEXT op is the only reader of this op's output buffer (set by build_graph)
   int up_consumer = -1;        // kUp: index of the 1x1 conv that can read the low-resolution source in place
   int up_from = -1;            // conv: index of the kUp op whose output slice it reads (then that op is skipped)
@@ -268,6 +269,18 @@ void build_graph(eioku_yolo* y) {
     for (const Op& o : y->ops) writers += (o.f32_out < 0 && o.out_buf == op.out_buf);
     op.sole_consumer = readers == 1 && writers == 1 && nx.in_buf == op.out_buf && nx.res_buf != op.out_buf &&
                        y->bufs[op.out_buf].ch == y->shapes[op.conv][0];
+    // weaker than sole_consumer: the buffer may be reused (C2f's tmp is shared by its bottlenecks) as long as every
+    // read of it is the op right after the write it consumes
+    bool priv = nx.in_buf == op.out_buf && nx.in_off == op.out_off && y->bufs[op.out_buf].ch == y->shapes[op.conv][0];
+    for (size_t j = 0; j < y->ops.size() && priv; ++j) {
+      const Op& o = y->ops[j];
+      if (o.res_buf == op.out_buf) priv = false;
+      if (o.in_buf == op.out_buf) {
+        const Op* pv = j > 0 ? &y->ops[j - 1] : nullptr;
+        priv = priv && pv && pv->kind == kConv && pv->f32_out < 0 && pv->out_buf == op.out_buf && pv->out_off == o.in_off;
+      }
+    }
+    op.chain_next = priv;
   }
 }
 
@@ -390,6 +403,20 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
       const bool pair = !first && nx && nx->kind == kConv && op.f32_out < 0 && op.res_buf < 0 && nx->res_buf < 0 &&
                         nx->f32_out < 0 && nx->in_buf == op.out_buf && nx->in_off == op.out_off && op.sole_consumer &&
                         conv_post_ok(cw, y->weights[nx->conv]);
+      // C2f Bottleneck (3x3 -> 3x3 [+ x]) on the shallow levels: one launch, the intermediate stays in LDS
+      const bool chain = !first && nx && nx->kind == kConv && op.f32_out < 0 && op.res_buf < 0 && nx->f32_out < 0 &&
+                         op.chain_next && conv_chain_ok(cw, y->weights[nx->conv]) &&
+                         (nx->res_buf < 0 || (nx->res_buf == op.in_buf && nx->res_off == op.in_off));
+      if (chain) {
+        const ConvWeights& bw = y->weights[nx->conv];
+        const Buf& ob2 = y->bufs[nx->out_buf];
+        rc = conv_chain_forward(cw, bw, in, n, H, W, Slice{ob2.ptr, ob2.ch, nx->out_off}, nx->res_buf >= 0, op.act, nx->act,
+                                stream);
+        flops += (cw.flops_per_pixel() + bw.flops_per_pixel()) * (double)n * H * W;
+        skip_next = true;
+        if (rc) return rc;
+        continue;
+      }
       if (pair) {
         const ConvWeights& pw = y->weights[nx->conv];
         const Buf& ob2 = y->bufs[nx->out_buf];

@@ -14,6 +14,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # a launch whose kernel carries POST = true (5th template argument) also ran the NEXT layer (3x3 + 1x1 pair): walk the
 # trace backwards from its end, one forward's worth of layers
 def is_pair(r):
+    if 'k_conv3x3_chain' in r['Kernel_Name']: return True  # Bottleneck: 3x3 -> 3x3 (+ x) in one launch
     m = re.search(r'k_conv3x3_persist<([^>]*)>', r['Kernel_Name'])
     return bool(m) and m.group(1).replace(' ', '').endswith(',true') and m.group(1).count(',') == 4
 pairs_layers = {'model.1.conv', 'model.3.conv'}
