@@ -69,6 +69,12 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
 bool conv_chain_ok(const ConvWeights& a, const ConvWeights& b);
 int conv_chain_forward(const ConvWeights& a, const ConvWeights& b, Slice in, int N, int H, int W, Slice out,
                        bool residual, int act_a, int act_b, hipStream_t stream);
+// YOLOv8n front end as one launch: fused letterbox (copy mode, 4-pixel aligned) -> stem (3 -> 16, s2) -> 3x3 s2
+// (16 -> 32) -> 1x1 (32 -> 32); H, W = letterboxed input size, `out` = the 1x1's output slice.  Bit-identical to the
+// separate launches (k_conv3x3_c8 + the 3x3+1x1 pair).
+bool conv_stem_chain_ok(const ConvWeights& stem, const ConvWeights& c1, const ConvWeights& post, const FusedInput& f, int W);
+int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, const ConvWeights& post, const FusedInput& f,
+                            int N, int H, int W, Slice out, int act0, int act1, int act2, hipStream_t stream);
 // `clsmax` (1x1, no activation, one cout tile): instead of the output tensor, per pixel one 64-bit word
 // (argmax channel << 32 | float bits of max_c(conv + bias)); ties go to the lower channel.
 bool conv_clsmax_ok(const ConvWeights& cw, int act);

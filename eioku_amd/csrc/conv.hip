@@ -1223,6 +1223,276 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// YOLOv8n front end as ONE launch: letterbox (copy mode) -> stem 3x3/s2 (3 -> 16) -> model.1 3x3/s2 (16 -> 32) ->
+// model.2.cv1 1x1 (32 -> 32).  Neither the fp16 network input nor the 320^2 x 16 stem output (105 MB per 64 frames,
+// written once and read 1.3x) ever exists in memory.  Per 8x16 tile of model.1's output the workgroup stages the
+// 35x67 image patch from the BGR bytes (8-byte RGB0 pixels, columns de-interleaved by parity for the stride-2
+// reads), runs the stem on the 17x33 pixels model.1 needs (36 fragments of 16 flattened patch pixels, 4-tap K
+// packing and weights in registers exactly as k_conv3x3_c8), writes act(stem) as fp16 into the LDS patch P1 (32 B
+// per pixel, zeros outside the map), runs model.1 out of P1 with the generic tap loop and hands its tile to the 1x1
+// as the POST path of k_conv3x3_persist does.  Every MFMA sees the operands of the separate launches in the same
+// k order, every intermediate is rounded to fp16 where they round it: the result is bit-identical.
+// model.1's K chunk is 16 real channels + 16 whose weights are zero: lanes of K groups 2, 3 re-read units 0, 1 of
+// P1 (finite values x 0) instead of a zero half that would double the patch.
+// ---------------------------------------------------------------------------------------------
+struct StemArgs {
+  const uint4* wgt;   // stem weights, packed [9 taps][16 rows][4 units]
+  const float* bias;
+  int act;
+  int H0, W0;         // network input (letterboxed) size
+};
+
+constexpr int kSX_H = 35, kSX_WH = 34, kSX_WS = 68, kSX_PX = kSX_H * kSX_WS;  // image patch, pixels (8 B each)
+constexpr int kSP_H = 17, kSP_W = 33, kSP_WH = 17, kSP_WS = 34, kSP_SLOTS = kSP_H * kSP_WS;  // P1, 32 B slots
+constexpr int kSC_WT1 = 9 * 32 * 4, kSC_WT2 = 32 * 4, kSC_T = 4 * 32 * 4;
+constexpr int kSC_P1_U = (kSP_SLOTS + 1) * 2;       // + one spare slot
+constexpr int kSC_XS_U = (kSX_PX + 2) / 2 + 1;      // + spare pixel, 16 B units
+constexpr size_t kStemChainLds = (size_t)(kSC_WT1 + kSC_WT2 + kSC_T + kSC_P1_U + kSC_XS_U) * 16;
+
+__global__ __launch_bounds__(256) void k_stem_chain(ConvArgs a, StemArgs st, FusedSrc fs, int total_tiles) {
+  constexpr int GPR = 18;                 // 4-pixel groups per patch row: columns -1 .. 70
+  constexpr int NG = kSX_H * GPR;         // 630
+  constexpr int RG = (NG + 255) / 256;    // 3 groups per thread
+  constexpr int NPA = kSP_H * kSP_W;      // 561 stem pixels per tile
+  constexpr int KA = (NPA + 63) / 64;     // 9 fragments per wave
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* wt1 = reinterpret_cast<uint4*>(smem);
+  uint4* wt2 = wt1 + kSC_WT1;
+  uint4* tbuf = wt2 + kSC_WT2;
+  uint4* p1 = tbuf + kSC_T;
+  unsigned char* xs = reinterpret_cast<unsigned char*>(p1 + kSC_P1_U);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4;
+  // staging groups
+  int g_y[RG], g_x[RG], g_off[RG][4];
+#pragma unroll
+  for (int j = 0; j < RG; ++j) {
+    const int g = tid + 256 * j;
+    const int gy = g / GPR, gx = g - gy * GPR;
+    g_y[j] = g < NG ? gy : -100000;  // an impossible row: the slot is then outside the network input
+    g_x[j] = 4 * gx - 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pc = 4 * gx - 1 + i;
+      g_off[j][i] = (g < NG && pc >= 0 && pc < 2 * kSX_WH - 1 ? gy * kSX_WS + (pc & 1) * kSX_WH + (pc >> 1) : kSX_PX) * 8;
+    }
+  }
+  const int tiles_per_img = a.tiles_w * a.tiles_h;
+  const float r_tpi = 1.0f / (float)tiles_per_img, r_tw = 1.0f / (float)a.tiles_w;
+  u32x3 graw[RG];
+  unsigned s_in = 0, s_img = 0;
+  int nx_n = 0, nx_th = 0, nx_tw = 0;
+  auto issue = [&](int tile) {
+    nx_n = fast_div(tile, tiles_per_img, r_tpi);
+    const int t2 = tile - nx_n * tiles_per_img;
+    nx_th = fast_div(t2, a.tiles_w, r_tw);
+    nx_tw = t2 - nx_th * a.tiles_w;
+    const int y0 = nx_th * (4 * kTH) - 3, x0 = nx_tw * (4 * kTW);
+    s_in = 0;
+    s_img = 0;
+#pragma unroll
+    for (int j = 0; j < RG; ++j) {
+      const int iy = y0 + g_y[j], ix = x0 + g_x[j];  // ix, W0, left and new_w are multiples of 4: a group is all in or all out
+      const bool in = (unsigned)iy < (unsigned)st.H0 && (unsigned)ix < (unsigned)st.W0;
+      const int y = iy - fs.top, x = ix - fs.left;
+      const bool img = in && (unsigned)y < (unsigned)fs.new_h && (unsigned)x < (unsigned)fs.new_w;
+      s_in |= (in ? 1u : 0u) << j;
+      s_img |= (img ? 1u : 0u) << j;
+      graw[j] = *reinterpret_cast<const u32x3*>(fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + y) * fs.src_w + x) * 3 : 0));
+    }
+  };
+
+  // stem: A operands (weights) live in registers; B operand of k-step j, K group q = the pixel of tap 4j+q
+  half8 wS[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int tap = 4 * j + q;
+    u32x4 v = u32x4{0, 0, 0, 0};
+    if (tap < 9) v = *reinterpret_cast<const u32x4*>(st.wgt + (tap * 16 + (lane & 15)) * 4);
+    wS[j] = __builtin_bit_cast(half8, v);
+  }
+  int tapoff[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    int tap = 4 * j + q;
+    if (tap > 8) tap = 8;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    tapoff[j] = (kh * kSX_WS + (kw == 1 ? kSX_WH : (kw == 2 ? 1 : 0))) * 8;
+  }
+  int xbase[KA], pa_st[KA], pa_yx[KA];
+#pragma unroll
+  for (int k = 0; k < KA; ++k) {
+    const int praw = (wave + 4 * k) * 16 + (lane & 15);
+    const int p = praw < NPA ? praw : NPA - 1;
+    const int py = p / kSP_W, px = p - py * kSP_W;
+    xbase[k] = (2 * py * kSX_WS + px) * 8;
+    pa_st[k] = (praw < NPA ? py * kSP_WS + (px & 1) * kSP_WH + (px >> 1) : kSP_SLOTS) * 32 + q * 8;
+    pa_yx[k] = (py << 8) | px;
+  }
+  const float4 biasS = *reinterpret_cast<const float4*>(st.bias + q * 4);
+  // model.1 out of P1
+  int bpos1[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int kh = tap / 3, kw = tap % 3;
+      const int ox = lane & 15;
+      const int slot = (2 * (wave * 2 + m) + kh) * kSP_WS + (kw == 1 ? kSP_WH + ox : (kw == 2 ? ox + 1 : ox));
+      bpos1[tap][m] = slot * 2 + (q & 1);
+    }
+  const int wsel = (lane & 15) * 4 + (q ^ ((lane >> 1) & 3));
+  const uint4* wt1_lane = wt1 + wsel;
+  const uint4* wt2_lane = wt2 + wsel;
+  float4 bias1[2], bias2[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    bias1[f] = *reinterpret_cast<const float4*>(a.bias + f * 16 + q * 4);
+    bias2[f] = *reinterpret_cast<const float4*>(a.post_bias + f * 16 + q * 4);
+  }
+
+  int tile = blockIdx.x;
+  if (tile < total_tiles) issue(tile);
+  {
+    constexpr int NW = kSC_WT1 + kSC_WT2, WB = 6;
+    for (int i0 = 0; i0 < NW; i0 += 256 * WB) {
+      u32x4 w[WB];
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int idx = i0 + j * 256 + tid;
+        const int k = idx < NW ? idx : 0;
+        w[j] = *reinterpret_cast<const u32x4*>(k < kSC_WT1 ? a.wgt + k : a.post_w + (k - kSC_WT1));
+      }
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int idx = i0 + j * 256 + tid;
+        const int row = ((idx < kSC_WT1 ? idx : idx - kSC_WT1) >> 2) & 31, unit = idx & 3;
+        if (idx < NW) *reinterpret_cast<u32x4*>(wt1 + (idx & ~3) + (unit ^ ((row >> 1) & 3))) = w[j];
+      }
+    }
+  }
+  for (; tile < total_tiles; tile += gridDim.x) {
+    // image patch -> LDS: BGR -> RGB, /255 as a multiply (same fp16, see k_conv3x3_c8), 114 grey outside the image,
+    // zero outside the network input (the stem's padding)
+#pragma unroll
+    for (int j = 0; j < RG; ++j) {
+      const bool in = (s_in >> j) & 1, img = (s_img >> j) & 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int byte = 3 * i + c;
+          v[c] = img ? (float)((graw[j][byte >> 2] >> (8 * (byte & 3))) & 0xffu) : 114.0f;
+        }
+        constexpr float k255 = 1.0f / 255.0f;
+        f16x4 lo = f16x4{(_Float16)(v[2] * k255), (_Float16)(v[1] * k255), (_Float16)(v[0] * k255), (_Float16)0.f};
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo);
+        *reinterpret_cast<u32x2*>(xs + g_off[j][i]) = in ? l2 : u32x2{0, 0};
+      }
+    }
+    __syncthreads();  // also orders the weight copy before the first tile
+    const int tn = nx_n, tth = nx_th, ttw = nx_tw;
+    const int next = tile + gridDim.x;
+    if (next < total_tiles) issue(next);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // stem on the 17x33 patch -> P1
+    const int r0 = tth * (2 * kTH) - 1, c0 = ttw * (2 * kTW) - 1;
+#pragma unroll
+    for (int k0 = 0; k0 < KA; k0 += 3) {
+      float4v acc[3];
+      half8 bf[3][3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(xs + xbase[k0 + m] + tapoff[j]);
+          bf[m][j] = __builtin_bit_cast(half8, u32x4{lo[0], lo[1], 0, 0});
+        }
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        acc[m] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wS[j], bf[m][j], acc[m], 0, 0, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int k = k0 + m;
+        const int ah = r0 + (pa_yx[k] >> 8), aw = c0 + (pa_yx[k] & 255);
+        const bool inmap = (unsigned)ah < (unsigned)a.H && (unsigned)aw < (unsigned)a.W;
+        float4v v = acc[m] + float4v{biasS.x, biasS.y, biasS.z, biasS.w};
+        if (st.act == kActSiLU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+        }
+        const f16x4 h = __builtin_convertvector(v, f16x4);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p1) + pa_st[k]) = inmap ? __builtin_bit_cast(u32x2, h) : u32x2{0, 0};
+      }
+    }
+    __syncthreads();
+
+    // model.1 (3x3 / s2) out of P1, then the 1x1 on the tile still on chip
+    float4v acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+    mma_taps<2, 2>(p1, wt1_lane, bpos1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    uint4* tw = tbuf + wave * 32 * 4;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const float4v v = activate_frag(a, acc[m][f], bias1[f]);
+        const f16x4 h = __builtin_convertvector(v, f16x4);
+        const int px = m * 16 + (lane & 15);
+        const int unit = f * 2 + (lane >> 5), half = q & 1;
+        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(tw + px * 4 + (unit ^ ((px >> 1) & 3))) + half * 8) = __builtin_bit_cast(u32x2, h);
+      }
+    __builtin_amdgcn_wave_barrier();
+    float4v acc2[2][2];
+    {
+      half8 bf[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int px = m * 16 + (lane & 15);
+        uint4 u = tw[px * 4 + (q ^ ((px >> 1) & 3))];
+        bf[m] = *reinterpret_cast<half8*>(&u);
+      }
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        uint4 w = wt2_lane[f * 64];
+        const half8 af = *reinterpret_cast<half8*>(&w);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          acc2[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[m], float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int ow = ttw * kTW + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int oh = tth * kTH + wave * 2 + m;
+      if (oh >= a.Ho || ow >= a.Wo) continue;
+      const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float4v v = acc2[m][f] + float4v{bias2[f].x, bias2[f].y, bias2[f].z, bias2[f].w};
+        if (a.post_act == kActSiLU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+        }
+        const f16x4 h = __builtin_convertvector(v, f16x4);
+        *reinterpret_cast<u32x2*>(a.post_out + opix * a.post_out_cs + f * 16 + q * 4) = __builtin_bit_cast(u32x2, h);
+      }
+    }
+  }
+}
+
 template <int NF, int S, int SRC>
 int launch_c8(const ConvArgs& a, const FusedSrc& fs, int ntiles, hipStream_t stream) {
   constexpr int PH = (kTH - 1) * S + 3, PW = (kTW - 1) * S + 3;
@@ -1610,13 +1880,71 @@ int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, i
   a.post_act = act_b;
   prof_start(EIOKU_PROF_CONV, stream);
   static const int db_env = getenv("EIOKU_CHAIN_DB") ? atoi(getenv("EIOKU_CHAIN_DB")) : -1;
-  // double-buffer the input patch while that still leaves two workgroups per CU
-  const bool db = db_env >= 0 ? db_env != 0 : chain_lds(ca.nf, true) <= 75 * 1024;
+  const bool db = db_env > 0;  // measured: the extra workgroup per CU beats the second patch buffer (69 vs 77 us at 160^2)
   int rc;
   if (ca.nf == 1) rc = db ? launch_chain<1, true>(a, stream) : launch_chain<1, false>(a, stream);
   else rc = db ? launch_chain<2, true>(a, stream) : launch_chain<2, false>(a, stream);
   prof_stop(EIOKU_PROF_CONV, stream);
   return rc;
+}
+
+bool conv_stem_chain_ok(const ConvWeights& stem, const ConvWeights& c1, const ConvWeights& post, const FusedInput& f,
+                        int W) {
+  static const bool off = getenv("EIOKU_STEM_CHAIN") && atoi(getenv("EIOKU_STEM_CHAIN")) == 0;
+  if (off) return false;
+  const bool shapes = stem.ks == 3 && stem.stride == 2 && stem.cin == 8 && stem.cout == 16 && stem.nf == 1 && stem.ntiles == 1 &&
+                      c1.ks == 3 && c1.stride == 2 && c1.cin == 16 && c1.cout == 32 && c1.nf == 2 && c1.ntiles == 1 &&
+                      c1.nchunks == 1 && post.ks == 1 && post.cin == 32 && post.cout == 32 && post.nf == 2 && post.ntiles == 1;
+  // copy-mode letterbox whose rows and padding are 4-pixel aligned (12-byte group loads)
+  const bool src = f.bgr != nullptr && f.mode == 0 && f.src_w % 4 == 0 && f.left % 4 == 0 && f.new_w % 4 == 0 && W % 4 == 0 &&
+                   ((uintptr_t)f.bgr & 3) == 0;
+  return shapes && src;
+}
+
+int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, const ConvWeights& post, const FusedInput& f,
+                            int N, int H, int W, Slice out, int act0, int act1, int act2, hipStream_t stream) {
+  EIOKU_REQUIRE(stem.d_w && c1.d_w && post.d_w && conv_stem_chain_ok(stem, c1, post, f, W), "layers cannot run as the fused front end");
+  EIOKU_REQUIRE(out.ptr && out.cstride % 4 == 0 && out.coff % 4 == 0, "bad output slice");
+  if (N == 0) return EIOKU_OK;
+  ConvArgs a{};
+  a.wgt = reinterpret_cast<const uint4*>(c1.d_w);
+  a.bias = c1.d_b;
+  a.N = N;
+  a.H = conv_out_dim(H, 3, 2);  // model.1's input = the stem's output map
+  a.W = conv_out_dim(W, 3, 2);
+  a.Cin = c1.cin;
+  a.Ho = conv_out_dim(a.H, 3, 2);
+  a.Wo = conv_out_dim(a.W, 3, 2);
+  a.Cout = c1.cout;
+  a.tiles_w = (a.Wo + kTW - 1) / kTW;
+  a.tiles_h = (a.Ho + kTH - 1) / kTH;
+  a.nchunks = 1;
+  a.act = act1;
+  a.post_w = reinterpret_cast<const uint4*>(post.d_w);
+  a.post_bias = post.d_b;
+  a.post_out = out.ptr + out.coff;
+  a.post_out_cs = out.cstride;
+  a.post_cout = post.cout;
+  a.post_act = act2;
+  StemArgs st{reinterpret_cast<const uint4*>(stem.d_w), stem.d_b, act0, H, W};
+  FusedSrc fs{f.bgr, f.src_h, f.src_w, f.new_h, f.new_w, f.top, f.left};
+  static bool attr_set = false;
+  if (!attr_set) {
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kStemChainLds));
+    attr_set = true;
+  }
+  const int total = a.tiles_w * a.tiles_h * N;
+  int per_cu = (int)(150 * 1024 / kStemChainLds);
+  static const int per_cu_env = getenv("EIOKU_STEM_CHAIN_WG") ? atoi(getenv("EIOKU_STEM_CHAIN_WG")) : 0;
+  if (per_cu_env > 0) per_cu = per_cu_env;
+  int bx = num_cus() * per_cu;
+  if (bx > total) bx = total;
+  prof_start(EIOKU_PROF_CONV, stream);
+  hipLaunchKernelGGL(k_stem_chain, dim3((unsigned)bx), dim3(256), kStemChainLds, stream, a, st, fs, total);
+  EIOKU_LAUNCH_CHECK();
+  prof_stop(EIOKU_PROF_CONV, stream);
+  return EIOKU_OK;
 }
 
 bool fused_input_ok(const ConvWeights& cw, const FusedInput& f, Slice res, const float* out_f32) {

@@ -374,10 +374,14 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
             int part = 0, bool clsmax = false, bool lazybox = false, bool lazydeep = false) {
   double flops = 0;
   bool skip_next = false;
-  int pool_skip = 0;
+  int pool_skip = 0, front_skip = 0;
   for (const Op& op : y->ops) {
     const bool is_first = &op == &y->ops.front();
     if ((part == 1 && !is_first) || (part == 2 && is_first)) continue;
+    if (front_skip > 0) {  // ran inside the fused front-end launch
+      --front_skip;
+      continue;
+    }
     if (skip_next) {  // this 1x1 ran inside the previous launch
       skip_next = false;
       continue;
@@ -403,6 +407,29 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
       const bool pair = !first && nx && nx->kind == kConv && op.f32_out < 0 && op.res_buf < 0 && nx->res_buf < 0 &&
                         nx->f32_out < 0 && nx->in_buf == op.out_buf && nx->in_off == op.out_off && op.sole_consumer &&
                         conv_post_ok(cw, y->weights[nx->conv]);
+      // fused-letterbox stem -> model.1 -> model.2.cv1 (YOLOv8n, copy-mode frames): one launch
+      if (first && fused && part == 0 && y->ops.size() > 2) {
+        const Op& o1 = y->ops[1];
+        const Op& o2 = y->ops[2];
+        const bool front = o1.kind == kConv && o2.kind == kConv && op.f32_out < 0 && op.res_buf < 0 && o1.f32_out < 0 &&
+                           o1.res_buf < 0 && o2.f32_out < 0 && o2.res_buf < 0 && o1.in_buf == op.out_buf &&
+                           o1.in_off == op.out_off && op.sole_consumer && o2.in_buf == o1.out_buf && o2.in_off == o1.out_off &&
+                           o1.sole_consumer &&
+                           conv_stem_chain_ok(cw, y->weights[o1.conv], y->weights[o2.conv], *fused, W);
+        if (front) {
+          const ConvWeights& w1 = y->weights[o1.conv];
+          const ConvWeights& w2 = y->weights[o2.conv];
+          const Buf& ob2 = y->bufs[o2.out_buf];
+          rc = conv_stem_chain_forward(cw, w1, w2, *fused, n, H, W, Slice{ob2.ptr, ob2.ch, o2.out_off}, op.act, o1.act, o2.act,
+                                       stream);
+          const int H1 = conv_out_dim(H, 3, 2), W1 = conv_out_dim(W, 3, 2);
+          const double px2 = (double)n * conv_out_dim(H1, 3, 2) * conv_out_dim(W1, 3, 2);
+          flops += cw.flops_per_pixel() * n * H1 * W1 + (w1.flops_per_pixel() + w2.flops_per_pixel()) * px2;
+          front_skip = 2;
+          if (rc) return rc;
+          continue;
+        }
+      }
       // C2f Bottleneck (3x3 -> 3x3 [+ x]) on the shallow levels: one launch, the intermediate stays in LDS
       const bool chain = !first && nx && nx->kind == kConv && op.f32_out < 0 && op.res_buf < 0 && nx->f32_out < 0 &&
                          op.chain_next && conv_chain_ok(cw, y->weights[nx->conv]) &&
