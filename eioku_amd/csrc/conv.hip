@@ -558,9 +558,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_flat(ConvArgs a, int npix, i
 // output tiles grid-stride, and the NEXT tile's halo patch is already in flight (registers) while the
 // current one is multiplied: one barrier per tile, HBM latency hidden behind the MFMAs.
 // ---------------------------------------------------------------------------------------------
-template <int NF, int S, int NCH, bool DB, bool POST = false>
-__global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_tiles) {
-  constexpr int KS = 3, TAPS = 9, PAD = 1;
+template <int NF, int S, int NCH, bool DB, bool POST = false, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void k_conv3x3_persist(ConvArgs a, int total_tiles) {
+  // NWV waves per workgroup, two output rows each: 8x16 tiles (4 waves) or, for the layers whose weight block leaves
+  // room for one workgroup per CU only, 16x16 tiles (8 waves: two waves per SIMD instead of one)
+  constexpr int KS = 3, TAPS = 9, PAD = 1, kTH = 2 * NWV, NT = 64 * NWV;
   constexpr int PH = (kTH - 1) * S + KS;
   constexpr int PW = (kTW - 1) * S + KS;
   constexpr int PWH = (PW + 1) / 2;
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
   constexpr int PATCH_U = PH * PWS * 4;           // per chunk
   constexpr int WT_U = TAPS * 16 * NF * 4;        // per chunk
   constexpr int NLOAD = PH * PW * 4 * NCH;        // staged units per tile
-  constexpr int R = (NLOAD + 255) / 256;          // per thread
+  constexpr int R = (NLOAD + NT - 1) / NT;          // per thread
   static_assert(R <= 32, "slot mask is one 32-bit word");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
   constexpr int NCH2 = (NF + 1) / 2;  // 32-channel chunks of the 1x1's K axis
   static_assert(!POST || NF % 2 == 0, "fused 1x1 needs a multiple of 32 intermediate channels");
   uint4* wt2 = patch + (DB ? 2 : 1) * NCH * PATCH_U + 1;     // [NCH2][16*NF][4]
-  uint4* tbuf = wt2 + NCH2 * 16 * NF * 4;                     // [4 waves][32][U1]
+  uint4* tbuf = wt2 + NCH2 * 16 * NF * 4;                     // [NWV waves][32][U1]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co_tile = blockIdx.y;
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
   unsigned s_live = 0;             // bit j: slot j fetches (inside the patch and below Cin)
 #pragma unroll
   for (int j = 0; j < R; ++j) {
-    const int idx = tid + 256 * j;
+    const int idx = tid + NT * j;
     const int cc = idx / (PH * PW * 4), rem = idx - cc * (PH * PW * 4);
     const int pix = rem >> 2, unit = rem & 3;
     const int py = pix / PW, px = pix - py * PW;
@@ -652,16 +654,16 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
     const uint4* wsrc = a.wgt + (size_t)co_tile * NCH * WT_U;
     constexpr int NW = NCH * WT_U;
     constexpr int WB = 8;  // loads in flight per thread
-    for (int i0 = 0; i0 < NW; i0 += 256 * WB) {
+    for (int i0 = 0; i0 < NW; i0 += NT * WB) {
       u32x4 w[WB];
 #pragma unroll
       for (int j = 0; j < WB; ++j) {
-        const int idx = i0 + j * 256 + tid;
+        const int idx = i0 + j * NT + tid;
         w[j] = *reinterpret_cast<const u32x4*>(wsrc + (idx < NW ? idx : 0));
       }
 #pragma unroll
       for (int j = 0; j < WB; ++j) {
-        const int idx = i0 + j * 256 + tid;
+        const int idx = i0 + j * NT + tid;
         const int row = (idx % WT_U) >> 2, unit = idx & 3;
         if (idx < NW) *reinterpret_cast<u32x4*>(wt + (idx & ~3) + (unit ^ ((row >> 1) & 3))) = w[j];
       }
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_persist(ConvArgs a, int total_t
   float4 biasr2[NF];
   const uint4* wt2_lane = wt2 + (lane & 15) * 4 + ((lane >> 4) ^ ((lane >> 1) & 3));
   if (POST) {
-    for (int idx = tid; idx < NCH2 * 16 * NF * 4; idx += 256) {
+    for (int idx = tid; idx < NCH2 * 16 * NF * 4; idx += NT) {
       const int row = (idx >> 2) % (16 * NF), unit = idx & 3;
       *reinterpret_cast<u32x4*>(wt2 + (idx & ~3) + (unit ^ ((row >> 1) & 3))) = *reinterpret_cast<const u32x4*>(a.post_w + idx);
     }
@@ -1523,34 +1525,39 @@ int launch_c8_dispatch(int nf, int src, const ConvArgs& a, const FusedSrc& fs, i
   return EIOKU_OK;
 }
 
-template <int NF, int S, int NCH, bool DB, bool POST = false>
-int launch_persist(const ConvArgs& a, int ntiles, hipStream_t stream) {
-  constexpr int PH = (kTH - 1) * S + 3, PW = (kTW - 1) * S + 3;
+template <int NF, int S, int NCH, bool DB, bool POST = false, int NWV = 4>
+int launch_persist(const ConvArgs& a_in, int ntiles, hipStream_t stream) {
+  constexpr int TH = 2 * NWV;
+  constexpr int PH = (TH - 1) * S + 3, PW = (kTW - 1) * S + 3;
   constexpr int PWS = (S == 2) ? 2 * ((PW + 1) / 2) : PW;
   constexpr size_t post_units = POST ? (size_t)((NF + 1) / 2) * 16 * NF * 4 + 4 * 32 * 2 * NF : 0;
   constexpr size_t lds = ((size_t)NCH * 9 * 16 * NF * 4 + (DB ? 2 : 1) * (size_t)NCH * PH * PWS * 4 + 1 + post_units) * 16;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_persist<NF, S, NCH, DB, POST>),
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_persist<NF, S, NCH, DB, POST, NWV>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  ConvArgs a = a_in;
+  a.tiles_h = (a.Ho + TH - 1) / TH;
   const int total = a.tiles_w * a.tiles_h * a.N;
-  int per_cu = (int)(150 * 1024 / lds);
+  // 160 KB of LDS per CU: two 78 KB workgroups do fit (measured on model.22.cv3.0.0, 68 -> 57 us)
+  static const int cu_kb = getenv("EIOKU_LDS_CU_KB") ? atoi(getenv("EIOKU_LDS_CU_KB")) : 160;
+  int per_cu = (int)((size_t)cu_kb * 1024 / lds);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
   int bx = num_cus() * per_cu / ntiles;
   if (bx < 1) bx = 1;
   if (bx > total) bx = total;
-  hipLaunchKernelGGL((k_conv3x3_persist<NF, S, NCH, DB, POST>), dim3((unsigned)bx, (unsigned)ntiles), dim3(256), lds,
+  hipLaunchKernelGGL((k_conv3x3_persist<NF, S, NCH, DB, POST, NWV>), dim3((unsigned)bx, (unsigned)ntiles), dim3(64 * NWV), lds,
                      stream, a, total);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }
 
 // LDS bytes of the persistent variant
-size_t persist_lds(int nf, int s, int nch, bool db) {
-  const int ph = (kTH - 1) * s + 3, pw = (kTW - 1) * s + 3;
+size_t persist_lds(int nf, int s, int nch, bool db, int th = kTH) {
+  const int ph = (th - 1) * s + 3, pw = (kTW - 1) * s + 3;
   const int pws = s == 2 ? 2 * ((pw + 1) / 2) : pw;
   return ((size_t)nch * 9 * 16 * nf * 4 + (db ? 2 : 1) * (size_t)nch * ph * pws * 4 + 1) * 16;
 }
@@ -1563,6 +1570,11 @@ int launch_persist_dispatch(int nf, int nch, bool db, const ConvArgs& a, int nti
     return db ? launch_persist<NF_, S, NCH_, true>(a, ntiles, stream) : launch_persist<NF_, S, NCH_, false>(a, ntiles, stream);
   EIOKU_P(1, 1) EIOKU_P(2, 1) EIOKU_P(3, 1) EIOKU_P(4, 1) EIOKU_P(5, 1) EIOKU_P(6, 1)
   EIOKU_P(1, 2) EIOKU_P(2, 2) EIOKU_P(3, 2) EIOKU_P(4, 2) EIOKU_P(5, 2)
+  // weight block too large for two workgroups per CU: one 8-wave workgroup with a 16x16 tile (two waves per SIMD)
+  static const bool w8_off = getenv("EIOKU_PERSIST_W8") && atoi(getenv("EIOKU_PERSIST_W8")) == 0;
+  if (S == 1 && !db && !w8_off && nf == 3 && nch == 3 && persist_lds(nf, S, nch, false) > 80 * 1024 &&
+      persist_lds(nf, S, nch, false, 16) <= 160 * 1024 && a.Ho > 8)
+    return launch_persist<3, S, 3, false, false, 8>(a, ntiles, stream);
   EIOKU_P(1, 3) EIOKU_P(2, 3) EIOKU_P(3, 3) EIOKU_P(4, 3) EIOKU_P(5, 3)
 #undef EIOKU_P
   *handled = false;
@@ -1752,7 +1764,7 @@ int pick_nf(int cout, int ks, int nchunks, int stride) {
     // two workgroups per CU with a single-buffered patch; otherwise fall through to the generic rule
     for (int nf : {4, 3, 2, 1}) {
       const int waste = ((frags + nf - 1) / nf) * nf - frags;
-      static const int lim_kb = getenv("EIOKU_PERSIST_KB") ? atoi(getenv("EIOKU_PERSIST_KB")) : 75;
+      static const int lim_kb = getenv("EIOKU_PERSIST_KB") ? atoi(getenv("EIOKU_PERSIST_KB")) : 79;  // two workgroups per 160 KB CU
       if (waste <= (frags >= 4 ? 1 : 0) && persist_lds(nf, stride, nchunks, false) <= (size_t)lim_kb * 1024) {
         // a 1-fragment tile re-reads the halo patch once per 16 couts and is LDS-read bound (3 reads per 2
         // MFMAs): with >= 5 fragments take 3 per tile even if only one workgroup then fits per CU

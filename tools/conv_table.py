@@ -18,7 +18,8 @@ def n_layers_of(r):
 def is_pair(r):
     if 'k_conv3x3_chain' in r['Kernel_Name']: return True  # Bottleneck: 3x3 -> 3x3 (+ x) in one launch
     m = re.search(r'k_conv3x3_persist<([^>]*)>', r['Kernel_Name'])
-    return bool(m) and m.group(1).replace(' ', '').endswith(',true') and m.group(1).count(',') == 4
+    args = m.group(1).replace(' ', '').split(',') if m else []
+    return len(args) >= 5 and args[4] == 'true'  # <NF, S, NCH, DB, POST[, waves]>
 pairs_layers = {'model.1.conv', 'model.3.conv'}
 def take(n_layers):
     out, i, need = [], len(rows) - 1, n_layers

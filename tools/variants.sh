@@ -9,5 +9,5 @@ for v in "$@"; do
   rm -rf /tmp/kt_$v
   timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$v -- python3 $R/bench.py --steps 4 --warmup 2 --stages detect --knn-n 0 --no-cpu-baseline --overlap 0 --depth 1 > /tmp/kt_$v.log 2>&1 || { tail -5 /tmp/kt_$v.log; exit 1; }
   echo "== $VAR=$v"
-  python3 $R/tools/conv_table.py /tmp/kt_$v n 64 | grep -E "^model\.[0-4]\.|TOTAL" | cut -c1-160
+  python3 $R/tools/conv_table.py /tmp/kt_$v n 64 | grep -E "${ROWS:-^model\.[0-4]\.|TOTAL}" | cut -c1-160
 done
