@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace eioku {
 
@@ -71,6 +72,20 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float silu_f32(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
+// Four values at once, the same operations bit for bit (__expf(-v) compiles to v_exp_f32(v * -log2e), the constant
+// being float(log2 e) = 0x3fb8aa3b): written on vectors so that the multiply and the +1 become v_pk_mul_f32 /
+// v_pk_add_f32 (two values per issue slot).  The epilogues of the shallow layers are VALU-bound, not MFMA-bound:
+// 918 VALU instructions per 67 MFMAs in k_stem_chain, a third of them SiLU.
+__device__ __forceinline__ float4v silu4(float4v v) {
+  const float4v t = v * float4v{-1.44269504088896340736f, -1.44269504088896340736f, -1.44269504088896340736f,
+                                -1.44269504088896340736f};
+  float4v d = float4v{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]),
+                      __builtin_amdgcn_exp2f(t[3])};
+  d = d + float4v{1.0f, 1.0f, 1.0f, 1.0f};
+  const float4v r = float4v{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]),
+                            __builtin_amdgcn_rcpf(d[3])};
+  return v * r;
+}
 
 // Epilogue for one accumulator fragment: the lane holds 4 consecutive couts c0..c0+3 of output pixel
 // `opix`: bias, SiLU, fp16 RNE, residual add (fp16(fp16(y) + x)), concat-slice store or fp32 store.
@@ -81,8 +96,7 @@ __device__ __forceinline__ float silu_f32(float v) {
 __device__ __forceinline__ float4v activate_frag(const ConvArgs& a, const float4v& acc, float4 b) {
   float4v v = acc + float4v{b.x, b.y, b.z, b.w};
   if (a.act == kActSiLU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = silu_f32(v[j]);
+    v = silu4(v);
   }
   return v;
 }
@@ -93,8 +107,7 @@ __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc
   if (c0 >= a.Cout) return;
   float4v v = acc + float4v{b.x, b.y, b.z, b.w};
   if (a.act == kActSiLU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = silu_f32(v[j]);
+    v = silu4(v);
   }
   const bool full = c0 + 3 < a.Cout;
   if (a.out_f32) {
@@ -983,8 +996,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, int total_til
         // Cout = 16*NF exactly: always the full-vector store of store_frag, same roundings
         float4v v = acc[m][f] + float4v{biasB[f].x, biasB[f].y, biasB[f].z, biasB[f].w};
         if (a.post_act == kActSiLU) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = silu_f32(v[j]);
+          v = silu4(v);
         }
         f16x4 h = __builtin_convertvector(v, f16x4);
         if (a.res) {
@@ -1285,6 +1297,7 @@ __global__ __launch_bounds__(256) void k_stem_chain(ConvArgs a, StemArgs st, Fus
   const float r_tpi = 1.0f / (float)tiles_per_img, r_tw = 1.0f / (float)a.tiles_w;
   u32x3 graw[RG];
   unsigned s_in = 0, s_img = 0;
+  bool s_full = false;
   int nx_n = 0, nx_th = 0, nx_tw = 0;
   auto issue = [&](int tile) {
     nx_n = fast_div(tile, tiles_per_img, r_tpi);
@@ -1294,6 +1307,8 @@ __global__ __launch_bounds__(256) void k_stem_chain(ConvArgs a, StemArgs st, Fus
     const int y0 = nx_th * (4 * kTH) - 3, x0 = nx_tw * (4 * kTW);
     s_in = 0;
     s_img = 0;
+    // every staged group (rows y0 .. y0+34, columns x0-4 .. x0+67) inside the image?
+    s_full = y0 >= fs.top && y0 + kSX_H <= fs.top + fs.new_h && x0 - 4 >= fs.left && x0 + 4 * GPR - 4 <= fs.left + fs.new_w;
 #pragma unroll
     for (int j = 0; j < RG; ++j) {
       const int iy = y0 + g_y[j], ix = x0 + g_x[j];  // ix, W0, left and new_w are multiples of 4: a group is all in or all out
@@ -1378,23 +1393,31 @@ __global__ __launch_bounds__(256) void k_stem_chain(ConvArgs a, StemArgs st, Fus
   for (; tile < total_tiles; tile += gridDim.x) {
     // image patch -> LDS: BGR -> RGB, /255 as a multiply (same fp16, see k_conv3x3_c8), 114 grey outside the image,
     // zero outside the network input (the stem's padding)
+    // (a patch wholly inside the image -- tile-uniform -- needs none of the per-pixel selects: the kernel is
+    // VALU-bound, see silu4)
+    auto commit = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int j = 0; j < RG; ++j) {
-      const bool in = (s_in >> j) & 1, img = (s_img >> j) & 1;
+      for (int j = 0; j < RG; ++j) {
+        const bool in = (s_in >> j) & 1, img = (s_img >> j) & 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v[3];
+        for (int i = 0; i < 4; ++i) {
+          float v[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const int byte = 3 * i + c;
-          v[c] = img ? (float)((graw[j][byte >> 2] >> (8 * (byte & 3))) & 0xffu) : 114.0f;
+          for (int c = 0; c < 3; ++c) {
+            const int byte = 3 * i + c;
+            const float fb = (float)((graw[j][byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+            v[c] = (FULL || img) ? fb : 114.0f;
+          }
+          constexpr float k255 = 1.0f / 255.0f;
+          f16x4 lo = f16x4{(_Float16)(v[2] * k255), (_Float16)(v[1] * k255), (_Float16)(v[0] * k255), (_Float16)0.f};
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo);
+          *reinterpret_cast<u32x2*>(xs + g_off[j][i]) = (FULL || in) ? l2 : u32x2{0, 0};
         }
-        constexpr float k255 = 1.0f / 255.0f;
-        f16x4 lo = f16x4{(_Float16)(v[2] * k255), (_Float16)(v[1] * k255), (_Float16)(v[0] * k255), (_Float16)0.f};
-        const u32x2 l2 = __builtin_bit_cast(u32x2, lo);
-        *reinterpret_cast<u32x2*>(xs + g_off[j][i]) = in ? l2 : u32x2{0, 0};
       }
-    }
+    };
+    if (s_full) commit(std::true_type{});
+    else commit(std::false_type{});
     __syncthreads();  // also orders the weight copy before the first tile
     const int tn = nx_n, tth = nx_th, ttw = nx_tw;
     const int next = tile + gridDim.x;
@@ -1403,6 +1426,7 @@ __global__ __launch_bounds__(256) void k_stem_chain(ConvArgs a, StemArgs st, Fus
 
     // stem on the 17x33 patch -> P1
     const int r0 = tth * (2 * kTH) - 1, c0 = ttw * (2 * kTW) - 1;
+    const bool p1_inside = r0 >= 0 && r0 + kSP_H <= a.H && c0 >= 0 && c0 + kSP_W <= a.W;
 #pragma unroll
     for (int k0 = 0; k0 < KA; k0 += 3) {
       float4v acc[3];
@@ -1423,15 +1447,18 @@ __global__ __launch_bounds__(256) void k_stem_chain(ConvArgs a, StemArgs st, Fus
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
         const int k = k0 + m;
-        const int ah = r0 + (pa_yx[k] >> 8), aw = c0 + (pa_yx[k] & 255);
-        const bool inmap = (unsigned)ah < (unsigned)a.H && (unsigned)aw < (unsigned)a.W;
         float4v v = acc[m] + float4v{biasS.x, biasS.y, biasS.z, biasS.w};
         if (st.act == kActSiLU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+          v = silu4(v);
         }
         const f16x4 h = __builtin_convertvector(v, f16x4);
-        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p1) + pa_st[k]) = inmap ? __builtin_bit_cast(u32x2, h) : u32x2{0, 0};
+        u32x2 hv = __builtin_bit_cast(u32x2, h);
+        if (!p1_inside) {  // tile-uniform: only border tiles pay for the per-pixel map test
+          const int ah = r0 + (pa_yx[k] >> 8), aw = c0 + (pa_yx[k] & 255);
+          const bool inmap = (unsigned)ah < (unsigned)a.H && (unsigned)aw < (unsigned)a.W;
+          hv = inmap ? hv : u32x2{0, 0};
+        }
+        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p1) + pa_st[k]) = hv;
       }
     }
     __syncthreads();
@@ -1485,8 +1512,7 @@ __global__ __launch_bounds__(256) void k_stem_chain(ConvArgs a, StemArgs st, Fus
       for (int f = 0; f < 2; ++f) {
         float4v v = acc2[m][f] + float4v{bias2[f].x, bias2[f].y, bias2[f].z, bias2[f].w};
         if (a.post_act == kActSiLU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu_f32(v[e]);
+          v = silu4(v);
         }
         const f16x4 h = __builtin_convertvector(v, f16x4);
         *reinterpret_cast<u32x2*>(a.post_out + opix * a.post_out_cs + f * 16 + q * 4) = __builtin_bit_cast(u32x2, h);
