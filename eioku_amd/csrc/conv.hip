@@ -146,41 +146,20 @@ __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc
 // B fragment (16 pixels x 32 channels = 16 B per lane) straight from HBM, one k-step ahead of the
 // MFMAs, and waves walk the pixel groups grid-stride with no barrier in the loop.
 // ---------------------------------------------------------------------------------------------
-template <int NF, bool UP = false>
-__global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
+template <int NF, bool UP = false, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void k_conv1x1(ConvArgs a, long long npix) {
+  constexpr int NT = 64 * NWV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* wt = reinterpret_cast<uint4*>(smem);  // [nchunks][16*NF][4 units], swizzled per row
   constexpr int ROWS = 16 * NF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co_tile = blockIdx.y;
-  {
-    // weight tile -> LDS, 8 loads in flight per thread (one load -> one store per iteration made this copy the
-    // longest phase of the low-resolution layers: 24 dependent round trips for Cin = 384)
-    const uint4* wsrc = a.wgt + (size_t)co_tile * a.nchunks * (ROWS * 4);
-    const int NW = a.nchunks * ROWS * 4;
-    constexpr int WB = 8;
-    for (int i0 = 0; i0 < NW; i0 += 256 * WB) {
-      u32x4 w[WB];
-#pragma unroll
-      for (int j = 0; j < WB; ++j) {
-        const int idx = i0 + j * 256 + tid;
-        w[j] = *reinterpret_cast<const u32x4*>(wsrc + (idx < NW ? idx : 0));
-      }
-#pragma unroll
-      for (int j = 0; j < WB; ++j) {
-        const int idx = i0 + j * 256 + tid;
-        const int row = (idx >> 2) % ROWS, unit = idx & 3;
-        if (idx < NW) *reinterpret_cast<u32x4*>(wt + (idx & ~3) + (unit ^ ((row >> 1) & 3))) = w[j];
-      }
-    }
-  }
-  __syncthreads();
 
   const int r = lane & 15, u = lane >> 4;
   const uint4* wt_lane = wt + r * 4 + (u ^ ((r >> 1) & 3));  // fragment (kc, f): + (kc*NF + f)*64 units
   const long long groups = (npix + 31) / 32;  // 32 pixels (2 fragments) per wave step
-  const long long gstride = (long long)gridDim.x * 4;
-  long long g = (long long)blockIdx.x * 4 + wave;
+  const long long gstride = (long long)gridDim.x * NWV;
+  long long g = (long long)blockIdx.x * NWV + wave;
 
   // B fragments are fetched KB k-steps (KB x 2 x 16 B per lane) at a time, one block ahead of the MFMAs.  The
   // loads are unconditional (pixel and chunk indices clamped into the tensor) so that the compiler counts them
@@ -217,7 +196,29 @@ __global__ __launch_bounds__(256) void k_conv1x1(ConvArgs a, long long npix) {
 #pragma unroll
   for (int f = 0; f < NF; ++f) biasr[f] = *reinterpret_cast<const float4*>(a.bias + co_tile * ROWS + f * 16 + u * 4);
   u32x4 bn[KB][2];
-  if (g < groups) load_blk(g, 0, bn);
+  if (g < groups) load_blk(g, 0, bn);  // in flight while the weight tile is copied
+  {
+    // weight tile -> LDS, 8 loads in flight per thread (one load -> one store per iteration made this copy the
+    // longest phase of the low-resolution layers: 24 dependent round trips for Cin = 384)
+    const uint4* wsrc = a.wgt + (size_t)co_tile * a.nchunks * (ROWS * 4);
+    const int NW = a.nchunks * ROWS * 4;
+    constexpr int WB = 8;
+    for (int i0 = 0; i0 < NW; i0 += NT * WB) {
+      u32x4 w[WB];
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int idx = i0 + j * NT + tid;
+        w[j] = *reinterpret_cast<const u32x4*>(wsrc + (idx < NW ? idx : 0));
+      }
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int idx = i0 + j * NT + tid;
+        const int row = (idx >> 2) % ROWS, unit = idx & 3;
+        if (idx < NW) *reinterpret_cast<u32x4*>(wt + (idx & ~3) + (unit ^ ((row >> 1) & 3))) = w[j];
+      }
+    }
+  }
+  __syncthreads();
   for (; g < groups; g += gstride) {
     float4v acc[2][NF];
 #pragma unroll
@@ -1743,29 +1744,40 @@ int launch_nf(int nf, const ConvArgs& a, int ntiles, hipStream_t stream) {
   return EIOKU_EINVAL;
 }
 
-template <int NF, bool UP>
-int launch1x1_impl(const ConvArgs& a, int ntiles, hipStream_t stream) {
+template <int NF, bool UP, int NWV>
+int launch1x1_impl(const ConvArgs& a, int ntiles, int wg_cu, hipStream_t stream) {
   const size_t lds = (size_t)a.nchunks * 16 * NF * 64;
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
-    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv1x1<NF, UP>),
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv1x1<NF, UP, NWV>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = lds;
   }
   const long long npix = (long long)a.N * a.H * a.W;
   const long long groups = (npix + 31) / 32;
-  long long bx = (groups + 3) / 4;
-  const long long cap = (long long)num_cus() * 8;  // grid-stride beyond ~8 workgroups per CU
+  long long bx = (groups + NWV - 1) / NWV;
+  const long long cap = (long long)num_cus() * wg_cu / ntiles;  // grid-stride beyond that many workgroups per CU
   if (bx > cap) bx = cap;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL((k_conv1x1<NF, UP>), dim3((unsigned)bx, (unsigned)ntiles), dim3(256), lds, stream, a, npix);
+  hipLaunchKernelGGL((k_conv1x1<NF, UP, NWV>), dim3((unsigned)bx, (unsigned)ntiles), dim3(64 * NWV), lds, stream, a, npix);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }
 
+// Workgroups per CU: few and persistent.  Measured on the 64-frame forward (19 1x1 layers, 8 -> 2 workgroups per
+// CU: 625 -> 555 us): every workgroup pays the weight-tile copy and its dispatch, and one-group-per-wave grids
+// (800 workgroups at 40x40) never reach the grid-stride loop that hides the load latency.  The widest tiles (NF = 8:
+// 64 MFMAs per pixel group and wave) are best with ONE workgroup per CU.
 template <int NF>
 int launch1x1(const ConvArgs& a, int ntiles, hipStream_t stream) {
-  return a.in2 ? launch1x1_impl<NF, true>(a, ntiles, stream) : launch1x1_impl<NF, false>(a, ntiles, stream);
+  static const int wg_env = getenv("EIOKU_1X1_WG") ? atoi(getenv("EIOKU_1X1_WG")) : 0;
+  static const int w8_env = getenv("EIOKU_1X1_W8") ? atoi(getenv("EIOKU_1X1_W8")) : 1;
+  const long long groups = ((long long)a.N * a.H * a.W + 31) / 32;
+  const bool fills = groups * ntiles / 8 >= (long long)num_cus() * 3 / 4;  // an 8-wave workgroup for (nearly) every CU
+  const bool w8 = fills && ((NF >= 8 && w8_env >= 1) || w8_env >= 2);
+  const int wg = wg_env > 0 ? wg_env : ((NF >= 8 || w8) ? 1 : 2);
+  if (w8) return a.in2 ? launch1x1_impl<NF, true, 8>(a, ntiles, wg, stream) : launch1x1_impl<NF, false, 8>(a, ntiles, wg, stream);
+  return a.in2 ? launch1x1_impl<NF, true, 4>(a, ntiles, wg, stream) : launch1x1_impl<NF, false, 4>(a, ntiles, wg, stream);
 }
 
 int launch1x1_nf(int nf, const ConvArgs& a, int ntiles, hipStream_t stream) {
