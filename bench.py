@@ -141,7 +141,7 @@ class Pipeline:
         if self.det is not None:
             ms, cnt = _lib.prof_read(_lib.PROF_CONV)
             flops_step = self.det.last_conv_flops()  # algorithmic 2*Cout*Cin*k*k per output pixel, whole batch
-            return {"kernel": "YOLOv8 conv family: k_conv3x3_persist / k_conv3x3_flat / k_conv1x1 (every conv launch of a step)", "bound": "mfma", "unit": "TFLOP/s",
+            return {"kernel": "YOLOv8 conv family: k_conv_stem_chain / k_conv3x3_chain / k_conv3x3_persist / k_conv3x3_flat / k_conv1x1 (every conv launch of a step)", "bound": "mfma", "unit": "TFLOP/s",
                     "peak": MFMA_F16_PEAK_TFLOPS, "alg_total": flops_step * self.prof_steps, "scale": 1e12,
                     "ms_total": ms, "launches": cnt, "alg_per_step": flops_step}
         ms, cnt = _lib.prof_read(_lib.PROF_SCENE_HSV)

@@ -75,7 +75,7 @@ __device__ __forceinline__ float silu_f32(float v) {
 // Four values at once, the same operations bit for bit (__expf(-v) compiles to v_exp_f32(v * -log2e), the constant
 // being float(log2 e) = 0x3fb8aa3b): written on vectors so that the multiply and the +1 become v_pk_mul_f32 /
 // v_pk_add_f32 (two values per issue slot).  The epilogues of the shallow layers are VALU-bound, not MFMA-bound:
-// 918 VALU instructions per 67 MFMAs in k_stem_chain, a third of them SiLU.
+// 918 VALU instructions per 67 MFMAs in k_conv_stem_chain, a third of them SiLU.
 __device__ __forceinline__ float4v silu4(float4v v) {
   const float4v t = v * float4v{-1.44269504088896340736f, -1.44269504088896340736f, -1.44269504088896340736f,
                                 -1.44269504088896340736f};
@@ -1265,7 +1265,7 @@ constexpr int kSC_P1_U = (kSP_SLOTS + 1) * 2;       // + one spare slot
 constexpr int kSC_XS_U = (kSX_PX + 2) / 2 + 1;      // + spare pixel, 16 B units
 constexpr size_t kStemChainLds = (size_t)(kSC_WT1 + kSC_WT2 + kSC_T + kSC_P1_U + kSC_XS_U) * 16;
 
-__global__ __launch_bounds__(256) void k_stem_chain(ConvArgs a, StemArgs st, FusedSrc fs, int total_tiles) {
+__global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st, FusedSrc fs, int total_tiles) {
   constexpr int GPR = 18;                 // 4-pixel groups per patch row: columns -1 .. 70
   constexpr int NG = kSX_H * GPR;         // 630
   constexpr int RG = (NG + 255) / 256;    // 3 groups per thread
@@ -1980,7 +1980,7 @@ int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, cons
   FusedSrc fs{f.bgr, f.src_h, f.src_w, f.new_h, f.new_w, f.top, f.left};
   static bool attr_set = false;
   if (!attr_set) {
-    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_stem_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)kStemChainLds));
     attr_set = true;
   }
@@ -1991,7 +1991,7 @@ int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, cons
   int bx = num_cus() * per_cu;
   if (bx > total) bx = total;
   prof_start(EIOKU_PROF_CONV, stream);
-  hipLaunchKernelGGL(k_stem_chain, dim3((unsigned)bx), dim3(256), kStemChainLds, stream, a, st, fs, total);
+  hipLaunchKernelGGL(k_conv_stem_chain, dim3((unsigned)bx), dim3(256), kStemChainLds, stream, a, st, fs, total);
   EIOKU_LAUNCH_CHECK();
   prof_stop(EIOKU_PROF_CONV, stream);
   return EIOKU_OK;

@@ -9,12 +9,12 @@ def level(name):
     if i == 22: return 3 + int(name.split('.')[3])
     return {0:0,1:1,2:2,3:2,4:3,5:3,6:4,7:4,8:5,9:5,12:4,15:3,16:3,18:4,19:4,21:5}[i]
 fs = sorted(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)
-rows = [r for r in csv.DictReader(open(fs[-1])) if ('k_conv' in r['Kernel_Name'] or 'k_stem_chain' in r['Kernel_Name']) and 'gather' not in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(fs[-1])) if ('k_conv' in r['Kernel_Name'] or 'stem_chain' in r['Kernel_Name']) and 'gather' not in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # a launch whose kernel carries POST = true (5th template argument) also ran the NEXT layer (3x3 + 1x1 pair): walk the
 # trace backwards from its end, one forward's worth of layers
 def n_layers_of(r):
-    return 3 if 'k_stem_chain' in r['Kernel_Name'] else (2 if is_pair(r) else 1)
+    return 3 if 'stem_chain' in r['Kernel_Name'] else (2 if is_pair(r) else 1)
 def is_pair(r):
     if 'k_conv3x3_chain' in r['Kernel_Name']: return True  # Bottleneck: 3x3 -> 3x3 (+ x) in one launch
     m = re.search(r'k_conv3x3_persist<([^>]*)>', r['Kernel_Name'])
@@ -33,7 +33,7 @@ lazy_names, last = set(), []
 for pat in (r'cv2\.\d\.[012]', r'cv2\.\d\.2$', None):
     names = {n for n, *_ in tab if pat and re.search(pat, n)}
     cand = take(len(tab) - len(names))
-    if cand and ('k_conv3x3_c8' in cand[0]['Kernel_Name'] or 'k_stem_chain' in cand[0]['Kernel_Name'] or pat is None):
+    if cand and ('k_conv3x3_c8' in cand[0]['Kernel_Name'] or 'stem_chain' in cand[0]['Kernel_Name'] or pat is None):
         lazy_names, last = names, cand
         break
 tot_t = tot_b = tot_f = 0
@@ -59,7 +59,7 @@ for (name, cout, cin, k, s) in tab:
     px_in, px_out = batch * hin * hin, batch * hout * hout
     obytes = 4 if re.search(r'cv[23]\.\d\.2$', name) else 2
     by = px_in * cin_eff * 2 + (0 if fused else px_out * cout * obytes)
-    if name == 'model.0.conv' and 'k_stem_chain' in r['Kernel_Name']:
+    if name == 'model.0.conv' and 'stem_chain' in r['Kernel_Name']:
         by = px_in * 3
     elif name == 'model.0.conv' and 'k_conv3x3_c8' in r['Kernel_Name'] and not re.search(r'c8<\d+, \d+, 0>', r['Kernel_Name']):
         by = px_in * 3 + px_out * cout * obytes  # fused letterbox: the stem reads the BGR u8 frames
@@ -67,7 +67,7 @@ for (name, cout, cin, k, s) in tab:
     fl = 2.0 * px_out * cout * cin * k * k
     us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     m_ = re.search(r'(k_conv\w+<[^>]*>)', r['Kernel_Name'])
-    kn = m_.group(1) if m_ else 'k_stem_chain'
+    kn = m_.group(1) if m_ else 'k_conv_stem_chain'
     tot_t += us; tot_b += by; tot_f += fl
     print(f"{name:28s} {cin:4d}->{cout:4d} k{k}s{s} @{hout:3d} {kn:28s} {int(r['Grid_Size_X'])//256:5d}x{r['Grid_Size_Y']:>3s} {us:7.1f} {by/1e6:7.1f} {by/us/1e3:6.0f} {fl/us/1e6:6.1f}")
 print(f"TOTAL {tot_t:.1f} us, {tot_b/1e9:.2f} GB -> {tot_b/tot_t/1e3:.0f} GB/s, {tot_f/1e9:.1f} GFLOP -> {tot_f/tot_t/1e6:.1f} TF/s")
