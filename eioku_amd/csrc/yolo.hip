@@ -313,6 +313,14 @@ void drop_graph(eioku_yolo* y) {
 
 int prepare(eioku_yolo* y, int n, int h, int w) {
   EIOKU_REQUIRE(h % 32 == 0 && w % 32 == 0, "network input %dx%d must be a multiple of 32", h, w);
+  // the conv kernels address activations with 32-bit element offsets and decode tile / pixel indices below 2^24
+  // (fast_div): a batch that breaks either must be split by the caller -- refuse it loudly
+  for (const auto& b : y->bufs) {
+    const long long px = (long long)n * level_dim(h, b.level) * level_dim(w, b.level);
+    EIOKU_REQUIRE(px * b.ch < (1ll << 31) && px < (1ll << 24) * 16,
+                  "batch of %d frames at %dx%d: an activation tensor of %lld x %d channels exceeds one launch's 32-bit "
+                  "offsets -- split the batch", n, h, w, px, b.ch);
+  }
   if (n != y->cur_n || h != y->cur_h || w != y->cur_w) y->gen++;  // buffers may move below
   for (auto& b : y->bufs) {
     const size_t bytes = (size_t)n * level_dim(h, b.level) * level_dim(w, b.level) * b.ch * sizeof(__half);

@@ -323,3 +323,19 @@ def test_detect_empty_batch_and_missing_weights(gpu):
     with pytest.raises(EiokuHipError):
         bare.detect(np.zeros((1, 64, 64, 3), dtype=np.uint8))
     bare.close()
+
+
+def test_batch_beyond_32bit_offsets_is_refused_not_corrupted(gpu):
+    """The conv kernels index activations with 32-bit element offsets: a batch whose tensors would overflow them must
+    fail loudly (split the batch) instead of reading out of bounds."""
+    import torch
+
+    from eioku_amd._lib import EiokuHipError
+
+    det = D.Yolov8Detector("n", 80, W.random_state("n", 80, seed=1))
+    frames = torch.zeros((140000, 64, 64, 3), dtype=torch.uint8, device="cuda")  # 140000 x 64 x 64 x 8 ch >= 2^31 elements
+    with pytest.raises(EiokuHipError, match="split the batch"):
+        det.detect(frames, conf=0.25)
+    dets, counts = det.detect(frames[:3], conf=0.25)  # the handle is still usable
+    assert counts.shape == (3,)
+    det.close()
