@@ -2021,6 +2021,12 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
   EIOKU_REQUIRE(!res.ptr || cw.cout < 4 || (res.cstride % 4 == 0 && res.coff % 4 == 0),
                 "residual slice must be 4-channel aligned");
   if (N == 0) return EIOKU_OK;
+  {
+    const long long px_in = (long long)N * H * W, px_out = (long long)N * conv_out_dim(H, cw.ks, cw.stride) * conv_out_dim(W, cw.ks, cw.stride);
+    const int ocs = out_f32 ? cw.cout : out.cstride;
+    EIOKU_REQUIRE(px_in * (in.cstride > 8 ? in.cstride : 8) < (1ll << 31) && px_out * (ocs > 1 ? ocs : 1) < (1ll << 31),
+                  "tensor of %lld pixels exceeds the kernels' 32-bit element offsets -- split the batch", px_in);
+  }
   ConvArgs a;
   a.in = in.ptr ? in.ptr + in.coff : nullptr;
   a.wgt = reinterpret_cast<const uint4*>(cw.d_w);
