@@ -1815,7 +1815,10 @@ int pick_nf(int cout, int ks, int nchunks, int stride) {
   int best = 1, best_waste = 1 << 30;
   for (int nf : cands) {
     if (ks == 3 && nf > 6) continue;  // LDS: 9 taps x 16*NF x 64 B
-    static const int lim1 = getenv("EIOKU_1X1_KB") ? atoi(getenv("EIOKU_1X1_KB")) : 128;  // measured: 8-wave NF=8 tiles with a 96-128 KB weight block beat 4 narrower cout tiles
+    // 64 KB: with 96-128 KB tiles (NF = 8, 8 waves) the 384/512-channel 1x1 layers are 2-4 us faster each in an
+    // isolated trace (-26 us per forward) but the overlapped step is not (40.5 vs 40.4 k frames/s) and the serial
+    // profiled step is slower: a workgroup holding most of a CU's LDS keeps the other streams' kernels off that CU
+    static const int lim1 = getenv("EIOKU_1X1_KB") ? atoi(getenv("EIOKU_1X1_KB")) : 64;
     if (ks == 1 && nf * nchunks > lim1 && nf > 1) continue;  // 1x1: the whole Cin x tile weight block lives in LDS (nf*nchunks KB)
     int waste = ((frags + nf - 1) / nf) * nf - frags;
     if (waste < best_waste) {
