@@ -1771,7 +1771,7 @@ int launch1x1_impl(const ConvArgs& a, int ntiles, int wg_cu, hipStream_t stream)
 template <int NF>
 int launch1x1(const ConvArgs& a, int ntiles, hipStream_t stream) {
   static const int wg_env = getenv("EIOKU_1X1_WG") ? atoi(getenv("EIOKU_1X1_WG")) : 0;
-  static const int w8_env = getenv("EIOKU_1X1_W8") ? atoi(getenv("EIOKU_1X1_W8")) : 1;
+  static const int w8_env = getenv("EIOKU_1X1_W8") ? atoi(getenv("EIOKU_1X1_W8")) : 0;
   const long long groups = ((long long)a.N * a.H * a.W + 31) / 32;
   const bool fills = groups * ntiles / 8 >= (long long)num_cus() * 3 / 4;  // an 8-wave workgroup for (nearly) every CU
   const bool w8 = fills && ((NF >= 8 && w8_env >= 1) || w8_env >= 2);
