@@ -673,13 +673,14 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
   lo[i] = l;
 }
 
-template <int EPI, bool WS>
+template <int EPI, bool WS, int BKS = 128>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                       const unsigned short* __restrict__ Whi,
                                                       const unsigned short* __restrict__ Wlo,
                                                       const float* __restrict__ bias, float* __restrict__ C, int ldc,
                                                       int M, int N, int K, int kstages) {
-  constexpr int BM = 64, BN = 64, BKS = 128;
+  constexpr int BM = 64, BN = 64;
+  constexpr int F4R = BKS / 4, RSTEP = 256 / F4R;  // float4 per staged row; rows covered by one pass of the 256 threads
   constexpr int PPR = BKS / 8;   // 8-k units per row and plane
   constexpr int UPR = 2 * PPR;   // [hi plane | lo plane]
   constexpr int RA = BM * (BKS / 4) / 256, RW = BN * (BKS / 4) / 256;  // float4 per thread and stage
@@ -693,20 +694,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int sfu = tid & 31, srow = tid >> 5;  // float4 index inside the staged row (k = 4 sfu ..), rows srow + 8 it
+  const int sfu = tid & (F4R - 1), srow = tid / F4R;  // float4 index inside the staged row (k = 4 sfu ..), rows srow + RSTEP it
   const int k0 = blockIdx.z * kstages * BKS;
   f32x4 ra[RA], rw[WS ? 1 : RW];
   u32x2b rwh[WS ? RW : 1], rwl[WS ? RW : 1];
   auto issue = [&](int st) {
 #pragma unroll
     for (int it = 0; it < RA; ++it) {
-      int m = m0 + srow + 8 * it;
+      int m = m0 + srow + RSTEP * it;
       if (m >= M) m = M - 1;
       ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + k0 + st * BKS + sfu * 4);
     }
 #pragma unroll
     for (int it = 0; it < RW; ++it) {
-      const size_t e = (size_t)(n0 + srow + 8 * it) * K + k0 + st * BKS + sfu * 4;
+      const size_t e = (size_t)(n0 + srow + RSTEP * it) * K + k0 + st * BKS + sfu * 4;
       if (WS) {
         rwh[it] = *reinterpret_cast<const u32x2b*>(Whi + e);
         rwl[it] = *reinterpret_cast<const u32x2b*>(Wlo + e);
@@ -716,13 +717,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
     }
   };
   auto put_split = [&](u32x4b* base, int row, u32x2b h, u32x2b l) {
-    const int p = (sfu >> 1) ^ (row & 15), sub = sfu & 1;
+    const int p = (sfu >> 1) ^ (row & (PPR - 1)), sub = sfu & 1;
     unsigned char* b = reinterpret_cast<unsigned char*>(base + row * UPR);
     *reinterpret_cast<u32x2b*>(b + p * 16 + sub * 8) = h;
     *reinterpret_cast<u32x2b*>(b + (PPR + p) * 16 + sub * 8) = l;
   };
   auto put = [&](u32x4b* base, int row, const f32x4& v) {
-    const int p = (sfu >> 1) ^ (row & 15), sub = sfu & 1;
+    const int p = (sfu >> 1) ^ (row & (PPR - 1)), sub = sfu & 1;
     unsigned h0, l0, h1, l1;
     split_bf16_pair(v[0], v[1], h0, l0);
     split_bf16_pair(v[2], v[3], h1, l1);
@@ -732,11 +733,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int it = 0; it < RA; ++it) put(sA, srow + 8 * it, ra[it]);
+    for (int it = 0; it < RA; ++it) put(sA, srow + RSTEP * it, ra[it]);
 #pragma unroll
     for (int it = 0; it < RW; ++it) {
-      if (WS) put_split(sW, srow + 8 * it, rwh[it], rwl[it]);
-      else put(sW, srow + 8 * it, rw[it]);
+      if (WS) put_split(sW, srow + RSTEP * it, rwh[it], rwl[it]);
+      else put(sW, srow + RSTEP * it, rw[it]);
     }
   };
   C += (size_t)blockIdx.z * M * ldc;
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
     const u32x4b* wp = sW + wrow * UPR;
 #pragma unroll
     for (int s8 = 0; s8 < BKS / 16; ++s8) {
-      const int pa = (2 * s8 + half) ^ (arow & 15), pw = (2 * s8 + half) ^ (wrow & 15);
+      const int pa = (2 * s8 + half) ^ (arow & (PPR - 1)), pw = (2 * s8 + half) ^ (wrow & (PPR - 1));
       const bf16x8 ah = __builtin_bit_cast(bf16x8, ap[pa]), al = __builtin_bit_cast(bf16x8, ap[PPR + pa]);
       const bf16x8 wh = __builtin_bit_cast(bf16x8, wp[pw]), wl = __builtin_bit_cast(bf16x8, wp[PPR + pw]);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
@@ -786,6 +787,8 @@ void launch_add_ln(const float* a, int nsplit, const float* abias, const float* 
 // of an [M x 384] output is ~100 workgroups on 256 CUs, each walking all of K serially; `splits` planes of
 // partial sums (summed, in plane order, by k_add_ln) put 2-4x as many workgroups on the chip.
 int pick_splits(int M, int N, int K) {
+  static const int forced = getenv("EIOKU_GEMM_SPLITS") ? atoi(getenv("EIOKU_GEMM_SPLITS")) : 0;  // A/B switch
+  if (forced > 0 && K % (128 * forced) == 0) return forced;
   if (M >= 8192) return 1;
   const int blocks = ((M + 63) / 64) * (N / 64);
   if (K % 128 == 0) {  // k_gemm_f32_s: stages of 128; the largest split <= kMaxSplit that divides them evenly
@@ -824,6 +827,12 @@ int gemm(const float* A, int lda, const float* W, const float* bias, float* C, i
       EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f32_s<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr = true;
     }
+    // small M (the ingest path: a few segments per call, running beside the detector): 64-deep stages = 32 KB of LDS
+    // per workgroup instead of 64.  The GEMM alone is as fast (0.457 vs 0.460 ms per 8 x 128 tokens) but two of its
+    // workgroups no longer take 128 of a CU's 160 KB away from the conv kernels on the other streams: +1.5 % on the
+    // overlapped step.  Same k order, so the results are bit-identical.
+    static const int bks_env = getenv("EIOKU_GEMM_BKS") ? atoi(getenv("EIOKU_GEMM_BKS")) : 0;
+    const bool bks64 = bks_env == 64 || (bks_env == 0 && M < 8192);
     const int kstages = K / 128 / splits;
     static const bool bf = !(getenv("EIOKU_GEMM_BF16") && atoi(getenv("EIOKU_GEMM_BF16")) == 0);
     static bool attr2 = false;
@@ -836,7 +845,9 @@ int gemm(const float* A, int lda, const float* W, const float* bias, float* C, i
     }
     const unsigned short* whi = ws ? ws->hi : nullptr;
     const unsigned short* wlo = ws ? ws->lo : nullptr;
-    if (bf && whi && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, true>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
+    if (bf && whi && bks64 && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, true, 64>), grid, dim3(256), lds / 2, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages * 2);
+    else if (bf && whi && bks64) hipLaunchKernelGGL((k_gemm_bf_s<0, true, 64>), grid, dim3(256), lds / 2, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages * 2);
+    else if (bf && whi && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, true>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
     else if (bf && whi) hipLaunchKernelGGL((k_gemm_bf_s<0, true>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
     else if (bf && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, false>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
     else if (bf) hipLaunchKernelGGL((k_gemm_bf_s<0, false>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
