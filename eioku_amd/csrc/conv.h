@@ -67,8 +67,13 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
 // Two chained 3x3 stride-1 layers with 16 / 32 channels (a C2f Bottleneck) as one launch: out = act_b(B(act_a(A(in))))
 // [+ in when `residual`]; the intermediate tensor stays in LDS.  Bit-identical to the two separate launches.
 bool conv_chain_ok(const ConvWeights& a, const ConvWeights& b);
+// `cat_w` (conv_chain_cat_ok: the 16-channel C2f with one Bottleneck): the C2f's closing 1x1 over the concat runs in
+// the same launch; `cat_in` = the concat buffer (its leading chunks are read from memory, the Bottleneck's output
+// stays on chip and `out` may be empty), `cat_out` = the 1x1's output slice.
+bool conv_chain_cat_ok(const ConvWeights& a, const ConvWeights& b, const ConvWeights& c2);
 int conv_chain_forward(const ConvWeights& a, const ConvWeights& b, Slice in, int N, int H, int W, Slice out,
-                       bool residual, int act_a, int act_b, hipStream_t stream);
+                       bool residual, int act_a, int act_b, hipStream_t stream, const ConvWeights* cat_w = nullptr,
+                       Slice cat_in = Slice{}, Slice cat_out = Slice{}, int cat_act = kActSiLU);
 // YOLOv8n front end as one launch: fused letterbox (copy mode, 4-pixel aligned) -> stem (3 -> 16, s2) -> 3x3 s2
 // (16 -> 32) -> 1x1 (32 -> 32); H, W = letterboxed input size, `out` = the 1x1's output slice.  Bit-identical to the
 // separate launches (k_conv3x3_c8 + the 3x3+1x1 pair).

@@ -815,8 +815,22 @@ __global__ __launch_bounds__(64 * NWV) void k_conv3x3_persist(ConvArgs a, int to
 // launches round them (fp16 intermediate, fp16(fp16(y) + x) residual), so the result is bit-identical.
 // HBM per pair: 1.9x-halo read + 1 write instead of 2 reads + residual read + 2 writes.
 // ---------------------------------------------------------------------------------------------
-template <int NF, bool DB>
-__global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, int total_tiles) {
+// CAT > 0 (C2f with one Bottleneck): the C2f's closing 1x1 over the concat [y0 | y1 | y2] runs here as well.  y2 =
+// this launch's output never leaves the CU: each wave writes its 32 pixels of it over the centre of the staged input
+// patch (its own residual pixels, already consumed), the CAT leading 32-channel chunks of the concat (y0 | y1) come
+// straight from HBM as B fragments (issued before conv A, so their latency is hidden), and the 1x1's weights sit in
+// LDS.  Same chunk order and operands as k_conv1x1: bit-identical.  model.2: -157 MB and one launch per forward.
+struct ChainCat {
+  const uint4* w;      // the 1x1's packed weights [(CAT + 1) chunks][16*NF2][4 units]
+  const float* bias;
+  __half* out;         // its output slice
+  int out_cs, act;
+  const __half* cat;   // channel 0 of the concat buffer
+  int cat_cs;
+};
+
+template <int NF, bool DB, int CAT = 0, int NF2 = 2>
+__global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, int total_tiles) {
   constexpr int XH = kTH + 4, XW = kTW + 4;  // input patch
   constexpr int PH = kTH + 2, PW = kTW + 2;  // intermediate patch
   constexpr int X_U = XH * XW * 4, P_U = PH * PW * 4;
@@ -832,6 +846,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, int total_til
   uint4* wtB = wtA + WT_U;
   uint4* xbuf = wtB + WT_U;                     // [DB ? 2 : 1][X_U] + 4 spare units
   uint4* p1 = xbuf + (DB ? 2 : 1) * X_U + 4;    // [P_U] + 4 spare units (stores of the last fragment's tail)
+  uint4* wt2 = p1 + P_U + 4;                    // CAT: [(CAT + 1)][16*NF2][4]
+  constexpr int W2_U = CAT > 0 ? (CAT + 1) * 16 * NF2 * 4 : 0;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int s_off[R], s_py[R], s_px[R], s_rel[R];
@@ -931,6 +947,18 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, int total_til
     }
     // channels 16*NF..31 of P1 are never written: they must read as zero, not as whatever LDS held
     for (int i = tid; i < P_U; i += 256) *reinterpret_cast<u32x4*>(p1 + i) = u32x4{0, 0, 0, 0};
+    if (CAT > 0) {
+      for (int idx = tid; idx < W2_U; idx += 256) {
+        const int row = (idx >> 2) % (16 * NF2), unit = idx & 3;
+        *reinterpret_cast<u32x4*>(wt2 + (idx & ~3) + (unit ^ ((row >> 1) & 3))) = *reinterpret_cast<const u32x4*>(cc.w + idx);
+      }
+    }
+  }
+  const uint4* wt2_lane = wt2 + wsel;
+  float4 bias2[NF2];
+  if (CAT > 0) {
+#pragma unroll
+    for (int f = 0; f < NF2; ++f) bias2[f] = *reinterpret_cast<const float4*>(cc.bias + f * 16 + (lane >> 4) * 4);
   }
   int buf = 0;
   for (; tile < total_tiles; tile += gridDim.x) {
@@ -945,6 +973,20 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, int total_til
     for (int j = 0; j < R; ++j) *reinterpret_cast<u32x4*>(xb + s_off[j]) = stage[j];
     __syncthreads();
     const int tn = nx_n, tth = nx_th, ttw = nx_tw;
+    // CAT: the concat's leading chunks for this wave's 32 pixels (clamped into the map), older than the next tile's
+    // prefetch in the vmcnt queue so that waiting for them leaves the prefetch in flight
+    u32x4 gB[CAT > 0 ? CAT : 1][2];
+    if (CAT > 0) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        int oh = tth * kTH + wave * 2 + m, owc = ttw * kTW + (lane & 15);
+        if (oh >= a.Ho) oh = a.Ho - 1;
+        if (owc >= a.Wo) owc = a.Wo - 1;
+        const __half* src = cc.cat + (((size_t)tn * a.Ho + oh) * a.Wo + owc) * cc.cat_cs + (lane >> 4) * 8;
+#pragma unroll
+        for (int c = 0; c < CAT; ++c) gB[c][m] = *reinterpret_cast<const u32x4*>(src + c * 32);
+      }
+    }
     const int next = tile + gridDim.x;
     if (next < total_tiles) issue(next);
     __builtin_amdgcn_sched_barrier(0);
@@ -990,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, int total_til
         const int unit = f * 2 + (lane >> 5), half = (lane >> 4) & 1;
         resv[f] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(xb + pos * 4 + (unit ^ ((pos >> 1) & 3))) + half * 8);
       }
-      if (oh >= a.Ho || ow >= a.Wo) continue;
+      if (CAT == 0 && (oh >= a.Ho || ow >= a.Wo)) continue;
       const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
@@ -1004,7 +1046,55 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, int total_til
           const float4v sum = __builtin_convertvector(h, float4v) + __builtin_convertvector(__builtin_bit_cast(f16x4, resv[f]), float4v);
           h = __builtin_convertvector(sum, f16x4);
         }
-        *reinterpret_cast<u32x2*>(a.post_out + opix * a.post_out_cs + f * 16 + (lane >> 4) * 4) = __builtin_bit_cast(u32x2, h);
+        if (CAT > 0) {  // y2 -> this pixel's slot of the staged patch (the residual above was its last reader)
+          const int unit = f * 2 + (lane >> 5), half = (lane >> 4) & 1;
+          *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(xb + pos * 4 + (unit ^ ((pos >> 1) & 3))) + half * 8) = __builtin_bit_cast(u32x2, h);
+        } else {
+          *reinterpret_cast<u32x2*>(a.post_out + opix * a.post_out_cs + f * 16 + (lane >> 4) * 4) = __builtin_bit_cast(u32x2, h);
+        }
+      }
+    }
+    if (CAT > 0) {
+      __builtin_amdgcn_wave_barrier();  // this wave's own LDS writes above, read back below: in order, no barrier needed
+      float4v acc2[2][NF2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) acc2[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c <= CAT; ++c) {
+        half8 bf[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          if (c < CAT) {
+            bf[m] = __builtin_bit_cast(half8, gB[c < CAT ? c : 0][m]);
+          } else {
+            const int pos = (2 + wave * 2 + m) * XW + 2 + (lane & 15);
+            uint4 u = xb[pos * 4 + ((lane >> 4) ^ ((pos >> 1) & 3))];
+            bf[m] = *reinterpret_cast<half8*>(&u);
+          }
+        }
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) {
+          uint4 w = wt2_lane[(c * NF2 + f) * 64];
+          const half8 af = *reinterpret_cast<half8*>(&w);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc2[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[m], acc2[m][f], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int oh = tth * kTH + wave * 2 + m;
+        if (oh >= a.Ho || ow >= a.Wo) continue;
+        const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) {
+          float4v v = acc2[m][f] + float4v{bias2[f].x, bias2[f].y, bias2[f].z, bias2[f].w};
+          if (cc.act == kActSiLU) v = silu4(v);
+          const f16x4 h = __builtin_convertvector(v, f16x4);
+          *reinterpret_cast<u32x2*>(cc.out + opix * cc.out_cs + f * 16 + (lane >> 4) * 4) = __builtin_bit_cast(u32x2, h);
+        }
       }
     }
     buf ^= 1;
@@ -1622,16 +1712,17 @@ int launch_persist_post_dispatch(int nf, int nch, bool db, const ConvArgs& a, hi
   return EIOKU_OK;
 }
 
-size_t chain_lds(int nf, bool db) {
-  return ((size_t)2 * 9 * 16 * nf * 4 + (db ? 2 : 1) * (size_t)(kTH + 4) * (kTW + 4) * 4 + 4 + (size_t)(kTH + 2) * (kTW + 2) * 4 + 4) * 16;
+size_t chain_lds(int nf, bool db, int cat_units = 0) {
+  return ((size_t)2 * 9 * 16 * nf * 4 + (db ? 2 : 1) * (size_t)(kTH + 4) * (kTW + 4) * 4 + 4 + (size_t)(kTH + 2) * (kTW + 2) * 4 + 4 +
+          cat_units) * 16;
 }
 
-template <int NF, bool DB>
-int launch_chain(const ConvArgs& a, hipStream_t stream) {
-  const size_t lds = chain_lds(NF, DB);
+template <int NF, bool DB, int CAT = 0, int NF2 = 2>
+int launch_chain(const ConvArgs& a, const ChainCat& cc, hipStream_t stream) {
+  const size_t lds = chain_lds(NF, DB, CAT > 0 ? (CAT + 1) * 16 * NF2 * 4 : 0);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_chain<NF, DB>),
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_chain<NF, DB, CAT, NF2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -1641,7 +1732,7 @@ int launch_chain(const ConvArgs& a, hipStream_t stream) {
   if (per_cu > 4) per_cu = 4;
   int bx = num_cus() * per_cu;
   if (bx > total) bx = total;
-  hipLaunchKernelGGL((k_conv3x3_chain<NF, DB>), dim3((unsigned)bx), dim3(256), lds, stream, a, total);
+  hipLaunchKernelGGL((k_conv3x3_chain<NF, DB, CAT, NF2>), dim3((unsigned)bx), dim3(256), lds, stream, a, cc, total);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }
@@ -1901,12 +1992,24 @@ bool conv_chain_ok(const ConvWeights& a, const ConvWeights& b) {
   return one(a) && one(b) && a.nf == b.nf;
 }
 
+bool conv_chain_cat_ok(const ConvWeights& a, const ConvWeights& b, const ConvWeights& c2) {
+  static const bool off = getenv("EIOKU_CHAIN_CAT") && atoi(getenv("EIOKU_CHAIN_CAT")) == 0;
+  // instantiated for the 16-channel C2f (YOLOv8n model.2): concat = [y0 | y1] (one 32-channel chunk from HBM) + y2
+  return !off && conv_chain_ok(a, b) && a.nf == 1 && c2.ks == 1 && c2.cin == 48 && c2.cout == 32 && c2.nf == 2 &&
+         c2.ntiles == 1 && c2.nchunks == 2;
+}
+
 int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, int N, int H, int W, Slice out,
-                       bool residual, int act_a, int act_b, hipStream_t stream) {
+                       bool residual, int act_a, int act_b, hipStream_t stream, const ConvWeights* cat_w, Slice cat_in,
+                       Slice cat_out, int cat_act) {
   EIOKU_REQUIRE(ca.d_w && cb.d_w && conv_chain_ok(ca, cb), "this pair of 3x3 layers cannot run as one launch");
-  EIOKU_REQUIRE(in.ptr && out.ptr && in.cstride % 8 == 0 && in.coff % 8 == 0 && out.cstride % 4 == 0 && out.coff % 4 == 0,
-                "bad slices");
+  EIOKU_REQUIRE(in.ptr && in.cstride % 8 == 0 && in.coff % 8 == 0, "bad input slice");
+  EIOKU_REQUIRE(cat_w || (out.ptr && out.cstride % 4 == 0 && out.coff % 4 == 0), "bad output slice");
+  EIOKU_REQUIRE(!cat_w || (cat_w->d_w && conv_chain_cat_ok(ca, cb, *cat_w) && cat_in.ptr && cat_in.cstride % 8 == 0 &&
+                           cat_in.coff % 8 == 0 && cat_out.ptr && cat_out.cstride % 4 == 0 && cat_out.coff % 4 == 0),
+                "the closing 1x1 cannot join this launch");
   if (N == 0) return EIOKU_OK;
+  EIOKU_REQUIRE((long long)N * H * W * in.cstride < (1ll << 31), "tensor exceeds 32-bit element offsets -- split the batch");
   ConvArgs a{};
   a.in = in.ptr + in.coff;
   a.wgt = reinterpret_cast<const uint4*>(ca.d_w);
@@ -1927,16 +2030,27 @@ int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, i
   a.act = act_a;
   a.post_w = reinterpret_cast<const uint4*>(cb.d_w);
   a.post_bias = cb.d_b;
-  a.post_out = out.ptr + out.coff;
+  a.post_out = out.ptr ? out.ptr + out.coff : nullptr;
   a.post_out_cs = out.cstride;
   a.post_cout = cb.cout;
   a.post_act = act_b;
+  ChainCat cc{};
+  if (cat_w) {
+    cc.w = reinterpret_cast<const uint4*>(cat_w->d_w);
+    cc.bias = cat_w->d_b;
+    cc.out = cat_out.ptr + cat_out.coff;
+    cc.out_cs = cat_out.cstride;
+    cc.act = cat_act;
+    cc.cat = cat_in.ptr + cat_in.coff;
+    cc.cat_cs = cat_in.cstride;
+  }
   prof_start(EIOKU_PROF_CONV, stream);
   static const int db_env = getenv("EIOKU_CHAIN_DB") ? atoi(getenv("EIOKU_CHAIN_DB")) : -1;
   const bool db = db_env > 0;  // measured: the extra workgroup per CU beats the second patch buffer (69 vs 77 us at 160^2)
   int rc;
-  if (ca.nf == 1) rc = db ? launch_chain<1, true>(a, stream) : launch_chain<1, false>(a, stream);
-  else rc = db ? launch_chain<2, true>(a, stream) : launch_chain<2, false>(a, stream);
+  if (cat_w) rc = launch_chain<1, false, 1, 2>(a, cc, stream);
+  else if (ca.nf == 1) rc = db ? launch_chain<1, true>(a, cc, stream) : launch_chain<1, false>(a, cc, stream);
+  else rc = db ? launch_chain<2, true>(a, cc, stream) : launch_chain<2, false>(a, cc, stream);
   prof_stop(EIOKU_PROF_CONV, stream);
   return rc;
 }

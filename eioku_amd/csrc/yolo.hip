@@ -445,6 +445,28 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
       if (chain) {
         const ConvWeights& bw = y->weights[nx->conv];
         const Buf& ob2 = y->bufs[nx->out_buf];
+        // ... and the C2f's closing 1x1 when this Bottleneck is the only one: concat = [y0 | y1 | y2], y2 = this pair's
+        // output (read by that 1x1 alone), y1 = this pair's input
+        const Op* n2 = (&op + 2 <= &y->ops.back()) ? &op + 2 : nullptr;
+        bool cat = n2 && n2->kind == kConv && n2->f32_out < 0 && n2->res_buf < 0 && n2->in_buf == nx->out_buf &&
+                   n2->in_off == 0 && op.in_buf == nx->out_buf && op.in_off == cw.cin && nx->out_off == 2 * cw.cin &&
+                   n2->in_ch == 3 * cw.cin && ob2.ch == 3 * cw.cin && conv_chain_cat_ok(cw, bw, y->weights[n2->conv]);
+        for (size_t j = 0; j < y->ops.size() && cat; ++j) {  // nobody else reads y2
+          const Op& o = y->ops[j];
+          if (&o == n2) continue;
+          if (o.in_buf == nx->out_buf && o.in_off + o.in_ch > nx->out_off) cat = false;
+          if (o.res_buf == nx->out_buf && o.res_off >= nx->out_off) cat = false;
+        }
+        if (cat) {
+          const ConvWeights& w2 = y->weights[n2->conv];
+          const Buf& ob3 = y->bufs[n2->out_buf];
+          rc = conv_chain_forward(cw, bw, in, n, H, W, Slice{}, nx->res_buf >= 0, op.act, nx->act, stream, &w2,
+                                  Slice{ob2.ptr, ob2.ch, 0}, Slice{ob3.ptr, ob3.ch, n2->out_off}, n2->act);
+          flops += (cw.flops_per_pixel() + bw.flops_per_pixel() + w2.flops_per_pixel()) * (double)n * H * W;
+          front_skip = 2;
+          if (rc) return rc;
+          continue;
+        }
         rc = conv_chain_forward(cw, bw, in, n, H, W, Slice{ob2.ptr, ob2.ch, nx->out_off}, nx->res_buf >= 0, op.act, nx->act,
                                 stream);
         flops += (cw.flops_per_pixel() + bw.flops_per_pixel()) * (double)n * H * W;

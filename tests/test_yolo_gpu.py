@@ -249,7 +249,7 @@ def test_fused_stem_equals_letterbox_then_network(gpu, h, w):
 def test_fused_3x3_1x1_pairs_are_bit_identical_to_separate_launches(gpu, variant, tmp_path):
     """model.1 -> model.2.cv1 and model.3 -> model.4.cv1 run as ONE launch (the 1x1 consumes the 3x3's tile on chip),
     the shallow C2f Bottlenecks (3x3 -> 3x3 + x, 16 / 32 channels) run as one launch with the intermediate in LDS
-    (EIOKU_CONV_CHAIN), and the neck's 1x1 convs read the half-resolution tensor in place instead of an upsampled copy.
+    (EIOKU_CONV_CHAIN; the 16-channel C2f's closing 1x1 joins that launch, EIOKU_CHAIN_CAT), and the neck's 1x1 convs read the half-resolution tensor in place instead of an upsampled copy.
     Same fp16 rounding of the intermediate, same MFMA k order: the Detect maps must equal, bit for bit, those of a
     process that runs every layer as its own launch (EIOKU_CONV_POST=0; the switch is read once per process)."""
     import os
@@ -271,7 +271,7 @@ def test_fused_3x3_1x1_pairs_are_bit_identical_to_separate_launches(gpu, variant
     for flag in ("1", "0"):
         path = tmp_path / f"heads_{flag}.npz"
         # every graph-level fusion on / off
-        env = dict(os.environ, EIOKU_CONV_POST=flag, EIOKU_UP_FUSE=flag, EIOKU_CONV_CHAIN=flag)
+        env = dict(os.environ, EIOKU_CONV_POST=flag, EIOKU_UP_FUSE=flag, EIOKU_CONV_CHAIN=flag, EIOKU_CHAIN_CAT=flag)
         subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=env, timeout=300)
         with np.load(path) as z:
             outs[flag] = [z[k] for k in z.files]

@@ -14,7 +14,12 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # a launch whose kernel carries POST = true (5th template argument) also ran the NEXT layer (3x3 + 1x1 pair): walk the
 # trace backwards from its end, one forward's worth of layers
 def n_layers_of(r):
-    return 3 if 'stem_chain' in r['Kernel_Name'] else (2 if is_pair(r) else 1)
+    if 'stem_chain' in r['Kernel_Name']: return 3
+    m = re.search(r'k_conv3x3_chain<([^>]*)>', r['Kernel_Name'])
+    if m:  # <NF, DB, CAT, NF2>: CAT > 0 = the C2f's closing 1x1 ran in the launch too
+        args = m.group(1).replace(' ', '').split(',')
+        return 3 if len(args) > 2 and args[2] not in ('0', 'false') else 2
+    return 2 if is_pair(r) else 1
 def is_pair(r):
     if 'k_conv3x3_chain' in r['Kernel_Name']: return True  # Bottleneck: 3x3 -> 3x3 (+ x) in one launch
     m = re.search(r'k_conv3x3_persist<([^>]*)>', r['Kernel_Name'])
