@@ -1647,7 +1647,7 @@ int launch_persist(const ConvArgs& a_in, int ntiles, hipStream_t stream) {
   constexpr int TH = 2 * NWV;
   constexpr int PH = (TH - 1) * S + 3, PW = (kTW - 1) * S + 3;
   constexpr int PWS = (S == 2) ? 2 * ((PW + 1) / 2) : PW;
-  constexpr size_t post_units = POST ? (size_t)((NF + 1) / 2) * 16 * NF * 4 + 4 * 32 * 2 * NF : 0;
+  constexpr size_t post_units = POST ? (size_t)((NF + 1) / 2) * 16 * NF * 4 + NWV * 32 * 2 * NF : 0;
   constexpr size_t lds = ((size_t)NCH * 9 * 16 * NF * 4 + (DB ? 2 : 1) * (size_t)NCH * PH * PWS * 4 + 1 + post_units) * 16;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
@@ -1703,6 +1703,12 @@ int launch_persist_dispatch(int nf, int nch, bool db, const ConvArgs& a, int nti
 template <int S>
 int launch_persist_post_dispatch(int nf, int nch, bool db, const ConvArgs& a, hipStream_t stream, bool* handled) {
   *handled = true;
+  // stride-2, 64 couts (model.3 -> model.4.cv1): 98 KB of LDS = one 4-wave workgroup per CU; the 8-wave 16x16-tile
+  // variant (149 KB) puts two waves on every SIMD: 54 -> 50 us alone, but the overlapped step is slower (41.8 vs 42.2 k
+  // frames/s: 149 KB leave no LDS for the other streams' workgroups), so it stays opt-in (EIOKU_POST_W8=1)
+  static const bool w8_off = getenv("EIOKU_PERSIST_W8") && atoi(getenv("EIOKU_PERSIST_W8")) == 0;
+  static const bool pw8 = getenv("EIOKU_POST_W8") && atoi(getenv("EIOKU_POST_W8")) != 0;
+  if (S == 2 && nf == 4 && nch == 1 && !db && !w8_off && pw8 && a.Ho > 8) return launch_persist<4, S, 1, false, true, 8>(a, 1, stream);
 #define EIOKU_PP(NF_, NCH_)                                                                             \
   if (nf == NF_ && nch == NCH_)                                                                          \
     return db ? launch_persist<NF_, S, NCH_, true, true>(a, 1, stream) : launch_persist<NF_, S, NCH_, false, true>(a, 1, stream);
