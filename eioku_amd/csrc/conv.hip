@@ -1733,7 +1733,7 @@ int launch_chain(const ConvArgs& a, const ChainCat& cc, hipStream_t stream) {
     attr_set = true;
   }
   const int total = a.tiles_w * a.tiles_h * a.N;
-  int per_cu = (int)(150 * 1024 / lds);
+  int per_cu = (int)(160 * 1024 / lds);  // two 80.3 KB workgroups (32-channel C2f + its closing 1x1) share a CU
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
   int bx = num_cus() * per_cu;
@@ -1998,11 +1998,21 @@ bool conv_chain_ok(const ConvWeights& a, const ConvWeights& b) {
   return one(a) && one(b) && a.nf == b.nf;
 }
 
+// concat = CAT whole 32-channel chunks from memory + this pair's 16*nf output channels; instantiated for YOLOv8n's
+// three shallow C2fs: (16 ch, 1 chunk, 32 couts), (32 ch, 2 or 3 chunks, 64 couts)
+int chain_cat_chunks(const ConvWeights& a, const ConvWeights& c2) {
+  const int c = 16 * a.nf, lead = c2.cin - c;
+  if (c2.ks != 1 || c2.ntiles != 1 || c2.cout != 16 * c2.nf || lead <= 0 || lead % 32 != 0) return 0;
+  const int cat = lead / 32;
+  if (a.nf == 1 && cat == 1 && c2.nf == 2) return 1;
+  static const int wide = getenv("EIOKU_CHAIN_CAT") ? atoi(getenv("EIOKU_CHAIN_CAT")) : 2;  // 1: the 16-channel C2f only
+  if (a.nf == 2 && (cat == 2 || cat == 3) && c2.nf == 4 && wide >= 2) return cat;
+  return 0;
+}
+
 bool conv_chain_cat_ok(const ConvWeights& a, const ConvWeights& b, const ConvWeights& c2) {
   static const bool off = getenv("EIOKU_CHAIN_CAT") && atoi(getenv("EIOKU_CHAIN_CAT")) == 0;
-  // instantiated for the 16-channel C2f (YOLOv8n model.2): concat = [y0 | y1] (one 32-channel chunk from HBM) + y2
-  return !off && conv_chain_ok(a, b) && a.nf == 1 && c2.ks == 1 && c2.cin == 48 && c2.cout == 32 && c2.nf == 2 &&
-         c2.ntiles == 1 && c2.nchunks == 2;
+  return !off && conv_chain_ok(a, b) && chain_cat_chunks(a, c2) > 0;
 }
 
 int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, int N, int H, int W, Slice out,
@@ -2054,7 +2064,11 @@ int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, i
   static const int db_env = getenv("EIOKU_CHAIN_DB") ? atoi(getenv("EIOKU_CHAIN_DB")) : -1;
   const bool db = db_env > 0;  // measured: the extra workgroup per CU beats the second patch buffer (69 vs 77 us at 160^2)
   int rc;
-  if (cat_w) rc = launch_chain<1, false, 1, 2>(a, cc, stream);
+  if (cat_w) {
+    const int cat = chain_cat_chunks(ca, *cat_w);
+    rc = cat == 1 ? launch_chain<1, false, 1, 2>(a, cc, stream)
+                  : (cat == 2 ? launch_chain<2, false, 2, 4>(a, cc, stream) : launch_chain<2, false, 3, 4>(a, cc, stream));
+  }
   else if (ca.nf == 1) rc = db ? launch_chain<1, true>(a, cc, stream) : launch_chain<1, false>(a, cc, stream);
   else rc = db ? launch_chain<2, true>(a, cc, stream) : launch_chain<2, false>(a, cc, stream);
   prof_stop(EIOKU_PROF_CONV, stream);

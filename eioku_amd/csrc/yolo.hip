@@ -445,12 +445,12 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
       if (chain) {
         const ConvWeights& bw = y->weights[nx->conv];
         const Buf& ob2 = y->bufs[nx->out_buf];
-        // ... and the C2f's closing 1x1 when this Bottleneck is the only one: concat = [y0 | y1 | y2], y2 = this pair's
-        // output (read by that 1x1 alone), y1 = this pair's input
+        // ... and the C2f's closing 1x1 when this is its LAST Bottleneck: concat = [y0 | y1 | .. | y_out], y_out = this
+        // pair's output (the concat's last slice, read by that 1x1 alone), the pair's input = the slice before it
         const Op* n2 = (&op + 2 <= &y->ops.back()) ? &op + 2 : nullptr;
         bool cat = n2 && n2->kind == kConv && n2->f32_out < 0 && n2->res_buf < 0 && n2->in_buf == nx->out_buf &&
-                   n2->in_off == 0 && op.in_buf == nx->out_buf && op.in_off == cw.cin && nx->out_off == 2 * cw.cin &&
-                   n2->in_ch == 3 * cw.cin && ob2.ch == 3 * cw.cin && conv_chain_cat_ok(cw, bw, y->weights[n2->conv]);
+                   n2->in_off == 0 && op.in_buf == nx->out_buf && nx->out_off == op.in_off + cw.cin &&
+                   n2->in_ch == nx->out_off + cw.cin && ob2.ch == n2->in_ch && conv_chain_cat_ok(cw, bw, y->weights[n2->conv]);
         for (size_t j = 0; j < y->ops.size() && cat; ++j) {  // nobody else reads y2
           const Op& o = y->ops[j];
           if (&o == n2) continue;
