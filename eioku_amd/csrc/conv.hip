@@ -1682,16 +1682,17 @@ size_t persist_lds(int nf, int s, int nch, bool db, int th = kTH) {
 template <int S>
 int launch_persist_dispatch(int nf, int nch, bool db, const ConvArgs& a, int ntiles, hipStream_t stream, bool* handled) {
   *handled = true;
-#define EIOKU_P(NF_, NCH_)                                                                    \
-  if (nf == NF_ && nch == NCH_)                                                                \
-    return db ? launch_persist<NF_, S, NCH_, true>(a, ntiles, stream) : launch_persist<NF_, S, NCH_, false>(a, ntiles, stream);
-  EIOKU_P(1, 1) EIOKU_P(2, 1) EIOKU_P(3, 1) EIOKU_P(4, 1) EIOKU_P(5, 1) EIOKU_P(6, 1)
-  EIOKU_P(1, 2) EIOKU_P(2, 2) EIOKU_P(3, 2) EIOKU_P(4, 2) EIOKU_P(5, 2)
   // weight block too large for two workgroups per CU: one 8-wave workgroup with a 16x16 tile (two waves per SIMD)
   static const bool w8_off = getenv("EIOKU_PERSIST_W8") && atoi(getenv("EIOKU_PERSIST_W8")) == 0;
   if (S == 1 && !db && !w8_off && nf == 3 && nch == 3 && persist_lds(nf, S, nch, false) > 80 * 1024 &&
       persist_lds(nf, S, nch, false, 16) <= 160 * 1024 && a.Ho > 8)
     return launch_persist<3, S, 3, false, false, 8>(a, ntiles, stream);
+  if (S == 1 && !db && !w8_off && nf == 5 && nch == 2 && a.Ho > 8) return launch_persist<5, S, 2, false, false, 8>(a, ntiles, stream);
+#define EIOKU_P(NF_, NCH_)                                                                    \
+  if (nf == NF_ && nch == NCH_)                                                                \
+    return db ? launch_persist<NF_, S, NCH_, true>(a, ntiles, stream) : launch_persist<NF_, S, NCH_, false>(a, ntiles, stream);
+  EIOKU_P(1, 1) EIOKU_P(2, 1) EIOKU_P(3, 1) EIOKU_P(4, 1) EIOKU_P(5, 1) EIOKU_P(6, 1)
+  EIOKU_P(1, 2) EIOKU_P(2, 2) EIOKU_P(3, 2) EIOKU_P(4, 2) EIOKU_P(5, 2)
   EIOKU_P(1, 3) EIOKU_P(2, 3) EIOKU_P(3, 3) EIOKU_P(4, 3) EIOKU_P(5, 3)
 #undef EIOKU_P
   *handled = false;
@@ -1894,6 +1895,11 @@ int launch1x1_nf(int nf, const ConvArgs& a, int ntiles, hipStream_t stream) {
 // Fewest padded channels first, then the widest tile (fewer re-reads of the input patch).
 int pick_nf(int cout, int ks, int nchunks, int stride) {
   const int frags = (cout + 15) / 16;
+  // 64 -> 80 (the class branch's first conv at P3): all 80 couts in one 8-wave workgroup (134 KB), the input staged
+  // once and no padded fragment, instead of 48 + 32 couts in two 78 KB workgroups.  Measured: 56.2 vs 56.7 us alone,
+  // 41.3 vs 41.3 k frames/s overlapped -- no gain, opt-in only (EIOKU_NF5=1)
+  static const bool nf5 = getenv("EIOKU_NF5") && atoi(getenv("EIOKU_NF5")) != 0;
+  if (nf5 && ks == 3 && stride == 1 && nchunks == 2 && frags == 5) return 5;
   if (ks == 3 && nchunks <= 3) {
     // persistent kernel: largest tile (<= 4 fragments, no padding waste beyond one fragment) that still fits
     // two workgroups per CU with a single-buffered patch; otherwise fall through to the generic rule
