@@ -254,6 +254,106 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
 // attention: grid (B, heads), PARTS lanes per query (each owns the keys j = part mod PARTS), block =
 // PARTS*S threads rounded to 64, head_dim == 32.  qkv: [B*S][3H] = Q | K | V; ctx: [B*S][H]
 // ---------------------------------------------------------------------------------------------
+// S <= 128: the whole (segment, head) on the exact-fp32 matrix core, one workgroup of 4 waves x 32 queries.
+// The scores are computed TRANSPOSED, S^T = K . Q^T (v_mfma_f32_32x32x2_f32: A = 32 keys x 2 dims, B = 2 dims x 32
+// queries), so that a lane ends up with one query (its column) and 64 of that query's 128 keys in its accumulator
+// registers, the other 64 in lane ^ 32: the softmax reductions are in-register plus ONE cross-lane exchange.  And
+// the accumulator registers are then already the B operand of O^T = V^T . P^T -- the k axis of an MFMA may be
+// summed in any order, so step r pairs exactly the two keys that register r holds in the two half-waves: no
+// transposition, no LDS round trip for P.  128 MFMAs per wave instead of ~12 k scalar FMAs per lane: 21 -> ~8 us.
+// Q / K rows are padded to 33 floats in LDS (a column read is then conflict-free); rows >= S are zero with mask 0.
+__global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict__ qkv, const uint8_t* __restrict__ mask, int S,
+                                                        int H, float* __restrict__ ctx) {
+  constexpr int SP = 128, QS = 33;
+  __shared__ float sQ[SP * QS];
+  __shared__ float sK[SP * QS];
+  __shared__ float sV[SP * 32];
+  __shared__ float sM[SP];
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row0 = (size_t)b * S;
+  for (int i0 = 0; i0 < SP * 8; i0 += 4 * 256) {
+    f32x4 qq[4], kk[4], vv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = i0 + t * 256 + tid;
+      const int j = (i >> 3) < S ? (i >> 3) : S - 1;
+      const float* base = qkv + (row0 + j) * (size_t)(3 * H) + h * 32 + (i & 7) * 4;
+      qq[t] = *reinterpret_cast<const f32x4*>(base);
+      kk[t] = *reinterpret_cast<const f32x4*>(base + H);
+      vv[t] = *reinterpret_cast<const f32x4*>(base + 2 * H);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = i0 + t * 256 + tid;
+      const int j = i >> 3, u = i & 7;
+      const bool in = j < S;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sQ[j * QS + u * 4 + e] = in ? qq[t][e] : 0.f;
+        sK[j * QS + u * 4 + e] = in ? kk[t][e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(&sV[j * 32 + u * 4]) = in ? vv[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  for (int j = tid; j < SP; j += 256) sM[j] = (j < S && mask[row0 + j]) ? 1.f : 0.f;
+  __syncthreads();
+  const int c = lane & 31, half = lane >> 5, q0 = wave * 32;
+  if (q0 >= S) return;  // a whole wave of padding queries (no barrier below)
+  float bq[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) bq[t] = sQ[(q0 + c) * QS + 2 * t + half];
+  f32x16 sc[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(kt * 32 + c) * QS + 2 * t + half], bq[t], sc[kt], 0, 0, 0);
+  }
+  // sc[kt][r] = <k_key, q_query>, key = kt*32 + (r & 3) + 8*(r >> 2) + 4*half, query = q0 + c
+  const float rinv = 0.17677669529663687f;  // 1 / sqrt(32)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float s = sM[key] != 0.f ? sc[kt][r] * rinv : -INFINITY;
+      sc[kt][r] = s;
+      mx = fmaxf(mx, s);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float l = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = sc[kt][r] != -INFINITY ? expf(sc[kt][r] - mx) : 0.f;
+      sc[kt][r] = e;
+      l += e;
+    }
+  l += __shfl_xor(l, 32, 64);
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[key * 32 + c], sc[kt][r], o, 0, 0, 0);
+    }
+  // o[r] = O[query][dim], dim = (r & 3) + 8*(r >> 2) + 4*half
+  const int qi = q0 + c;
+  if (qi >= S) return;
+  const float rl = l > 0.f ? 1.0f / l : 0.f;  // fully masked segment -> zeros (its pooled vector is 0 anyway)
+  float* op = ctx + (row0 + qi) * (size_t)H + h * 32;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<f32x4*>(op + 8 * g + 4 * half) = f32x4{o[4 * g] * rl, o[4 * g + 1] * rl, o[4 * g + 2] * rl, o[4 * g + 3] * rl};
+}
+
 // S <= 256: 8 lanes per query (keys j = lane, lane + 8, ...), 32 queries per workgroup.  Each lane keeps its <= 32
 // scores in registers (the old kernel computed every score twice: once for the max, once for the exponent) and
 // the K / V rows are swizzled by row so that the 8 rows a query group reads at once hit 8 different bank groups.
@@ -1052,7 +1152,10 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
     const std::string p = "encoder.layer." + std::to_string(l) + ".";
     if ((rc = gemm(m->x, H, tp(m, p + "attention.self.query.weight"), tp(m, p + "attention.self.query.bias"), m->qkv,
                    3 * H, T, 3 * H, H, 0, 1, stream, &m->wsplit[(size_t)4 * l + 0]))) return rc;
-    if (parts == 4)
+    static const bool amfma = !(getenv("EIOKU_ATTN_MFMA") && atoi(getenv("EIOKU_ATTN_MFMA")) == 0);
+    if (amfma && S <= 128 && H == m->heads * 32)
+      hipLaunchKernelGGL(k_attention_mfma, dim3(B, m->heads), dim3(256), 0, stream, m->qkv, d_mask, S, H, m->ctx);
+    else if (parts == 4)
       hipLaunchKernelGGL(k_attention8, dim3(B, m->heads, qsplit), dim3(256), alds, stream, m->qkv, d_mask, S, H, m->ctx);
     else
       hipLaunchKernelGGL(k_attention<1>, dim3(B, m->heads), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
