@@ -261,12 +261,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
 // the accumulator registers are then already the B operand of O^T = V^T . P^T -- the k axis of an MFMA may be
 // summed in any order, so step r pairs exactly the two keys that register r holds in the two half-waves: no
 // transposition, no LDS round trip for P.  128 MFMAs per wave instead of ~12 k scalar FMAs per lane: 21 -> ~8 us.
-// Q / K rows are padded to 33 floats in LDS (a column read is then conflict-free); rows >= S are zero with mask 0.
+// Q / K columns are XOR-swizzled by the row in LDS (a column read is then conflict-free); rows >= S are zero, mask 0.
 __global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict__ qkv, const uint8_t* __restrict__ mask, int S,
                                                         int H, float* __restrict__ ctx) {
-  constexpr int SP = 128, QS = 33;
-  __shared__ float sQ[SP * QS];
-  __shared__ float sK[SP * QS];
+  constexpr int SP = 128, QS = 32;
+  __shared__ __attribute__((aligned(16))) float sQ[SP * QS];
+  __shared__ __attribute__((aligned(16))) float sK[SP * QS];
   __shared__ float sV[SP * 32];
   __shared__ float sM[SP];
   const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -287,11 +287,17 @@ __global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict_
       const int i = i0 + t * 256 + tid;
       const int j = i >> 3, u = i & 7;
       const bool in = j < S;
+      // element (j, d) of Q / K lives at column d ^ (j & 31): a column read over 32 consecutive rows then touches 32
+      // different banks, and an aligned group of 4 dims stays one (permuted) 16-byte store
+      const int pj = j & 3, gu = (u ^ ((j >> 2) & 7)) * 4;
+      f32x4 qp, kp;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        sQ[j * QS + u * 4 + e] = in ? qq[t][e] : 0.f;
-        sK[j * QS + u * 4 + e] = in ? kk[t][e] : 0.f;
+        qp[e] = in ? qq[t][e ^ pj] : 0.f;
+        kp[e] = in ? kk[t][e ^ pj] : 0.f;
       }
+      *reinterpret_cast<f32x4*>(&sQ[j * QS + gu]) = qp;
+      *reinterpret_cast<f32x4*>(&sK[j * QS + gu]) = kp;
       *reinterpret_cast<f32x4*>(&sV[j * 32 + u * 4]) = in ? vv[t] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict_
   if (q0 >= S) return;  // a whole wave of padding queries (no barrier below)
   float bq[16];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) bq[t] = sQ[(q0 + c) * QS + 2 * t + half];
+  for (int t = 0; t < 16; ++t) bq[t] = sQ[(q0 + c) * QS + ((2 * t + half) ^ c)];  // (q0 + c) & 31 == c
   f32x16 sc[4];
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict_
     for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t)
-      sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(kt * 32 + c) * QS + 2 * t + half], bq[t], sc[kt], 0, 0, 0);
+      sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(kt * 32 + c) * QS + ((2 * t + half) ^ c)], bq[t], sc[kt], 0, 0, 0);
   }
   // sc[kt][r] = <k_key, q_query>, key = kt*32 + (r & 3) + 8*(r >> 2) + 4*half, query = q0 + c
   const float rinv = 0.17677669529663687f;  // 1 / sqrt(32)
