@@ -271,7 +271,9 @@ def test_fused_3x3_1x1_pairs_are_bit_identical_to_separate_launches(gpu, variant
     for flag in ("1", "0"):
         path = tmp_path / f"heads_{flag}.npz"
         # every graph-level fusion on / off
-        env = dict(os.environ, EIOKU_CONV_POST=flag, EIOKU_UP_FUSE=flag, EIOKU_CONV_CHAIN=flag, EIOKU_CHAIN_CAT=flag)
+        # (EIOKU_CHAIN_CAT: 2 = every C2f whose closing 1x1 can join its last Bottleneck, the default; 0 = none)
+        env = dict(os.environ, EIOKU_CONV_POST=flag, EIOKU_UP_FUSE=flag, EIOKU_CONV_CHAIN=flag,
+                   EIOKU_CHAIN_CAT="2" if flag == "1" else "0")
         subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=env, timeout=300)
         with np.load(path) as z:
             outs[flag] = [z[k] for k in z.files]
