@@ -73,6 +73,9 @@ SIGNATURES = {
     "eioku_index_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "eioku_index_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_void_p]),
+    "eioku_index_search_after": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_void_p]),
+    "eioku_index_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong]),
     "eioku_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
     "eioku_bert_create": (C.c_int, [C.c_int] * 7 + [C.c_float, C.POINTER(C.c_void_p)]),

@@ -72,6 +72,12 @@ struct KnnArgs {
   float* pd;                 // partial [gridDim.y][gridDim.x][kQT][K]
   int* pi;
   long long id_base;         // added to row ids at the very end (kept in merge)
+  // optional exclusive lower bound per query (eioku_index_search_after): only rows with
+  // (dist, id) > (lbd[q], lbi[q]) lexicographically are candidates.  NULL = no bound.
+  const float* lbd;
+  const long long* lbi;
+  long long slab_stride;     // rows between slab starts (== rows_per_block for a full search; larger = strided sample)
+  const int* gate;           // optional device word: the launch is a no-op when *gate == 0 (scan-path fallback)
 };
 
 // Query tile (32 x d) in registers, DB streamed through LDS.
@@ -85,6 +91,7 @@ struct KnnArgs {
 // the epilogue issues no global load that would drain the in-order vmcnt queue.
 template <int K, int D, bool WIDE>
 __global__ __launch_bounds__(256, 1) void k_flat_l2(KnnArgs a) {
+  if (a.gate && *a.gate == 0) return;  // uniform
   constexpr int KC = D < 128 ? D : 128;  // dims per LDS chunk (<= 512 B per row)
   constexpr int NCH = D / KC;            // chunks per row
   constexpr int UPR = KC / 4;          // 16-byte units per row chunk
@@ -116,11 +123,14 @@ __global__ __launch_bounds__(256, 1) void k_flat_l2(KnnArgs a) {
     }
   }
   const float qn = qvalid ? a.qnorm[qi] : 0.f;
+  const bool bounded = a.lbd != nullptr;
+  const float lbd = bounded && qvalid ? a.lbd[qi] : -1.f;
+  const long long lbi = bounded && qvalid ? a.lbi[qi] : -1;
 
   TopK<K> top;
   top.init();
 
-  const long long slab0 = (long long)blockIdx.x * a.rows_per_block;
+  const long long slab0 = (long long)blockIdx.x * a.slab_stride;
   const long long slab1 = min(a.n, slab0 + a.rows_per_block);
   float4* my = lds + (WIDE ? 0 : wave) * (2 * TILE_U);
   float* mynorm = lnorm + (WIDE ? 0 : wave) * (2 * kRT);
@@ -214,7 +224,8 @@ __global__ __launch_bounds__(256, 1) void k_flat_l2(KnnArgs a) {
             float dist = (qn + mynorm[nbuf * kRT + lr]) - 2.0f * acc[r];
             dist = dist < 0.f ? 0.f : dist;
             const int id = (int)(row - slab0);  // slab-local, fits 31 bits
-            if (top.beats_tail(dist, id)) top.insert(dist, id);
+            const bool after = !bounded || dist > lbd || (dist == lbd && row > lbi);
+            if (after && top.beats_tail(dist, id)) top.insert(dist, id);
           }
           acc[r] = 0.f;
         }
@@ -295,6 +306,7 @@ __device__ __forceinline__ void split_bf16x2(float a, float b, unsigned& hi, uns
 
 template <int K, int D>
 __global__ __launch_bounds__(256, 1) void k_flat_l2_bf(KnnArgs a) {
+  if (a.gate && *a.gate == 0) return;  // uniform
   constexpr int KC = D < 128 ? D : 128;  // dims per LDS chunk
   constexpr int NCH = D / KC;
   constexpr int NS = KC / 16;            // 16-dim MFMA steps per chunk
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void k_flat_l2_bf(KnnArgs a) {
   TopK<K> top;
   top.init();
 
-  const long long slab0 = (long long)blockIdx.x * a.rows_per_block;
+  const long long slab0 = (long long)blockIdx.x * a.slab_stride;
   const long long slab1 = min(a.n, slab0 + a.rows_per_block);
   // register ring two tiles deep: tile t+2 is requested while tile t is multiplied (2 x NCH x 16 KB in flight per CU)
   float4 stage[2][NCH][SPT];
@@ -506,7 +518,8 @@ template <int K>
 __global__ __launch_bounds__(64) void k_topk_merge(const float* pd, const int* pi, const long long* pi64,
                                                    int L, int nq, int kin, int qstride_lists,
                                                    const long long* list_base, long long rows_per_list,
-                                                   int k, float* D, long long* I) {
+                                                   int k, float* D, long long* I, const int* gate = nullptr) {
+  if (gate && *gate == 0) return;
   const int q = blockIdx.x, lane = threadIdx.x;
   // partial layout: [qtile][list][kQT][kin] when qstride_lists > 0 (search partials), else [list][nq][kin]
   TopK<K> top;
@@ -578,6 +591,358 @@ __global__ __launch_bounds__(64) void k_topk_merge(const float* pd, const int* p
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Scan path (nq > 64, large N): database-tile stationary.
+//
+// The kernels above keep a 32-query tile in registers and stream the database past it, so a 1024-query
+// search reads the database 8 times (once per 128 queries).  Here the roles are swapped: a wave keeps a tile
+// of 32 database rows in registers as the MFMA A operand (pre-split bf16 planes, fragment-tiled at add/attach
+// time so that a lane's fragment is one coalesced 16-byte load) and ALL query tiles stream past it through
+// LDS (LDS-DMA, one tile ahead; the query planes are 0.75-1.5 MB and live in every XCD's L2).  HBM sees each
+// plane exactly once per search and the kernel is bound by the bf16 matrix pipe.
+//
+// A row-stationary wave meets every query, so per-query top-k lists cannot live in its registers.  Instead a
+// per-query upper bound tau_q on the k-th distance comes from an exact search of a strided SAMPLE of the rows
+// (the k-th best of any subset bounds the k-th best of the whole), the scan appends every (query, row) whose
+// distance is <= tau_q to that query's candidate list (expected k * N / S entries), and k_scan_select picks
+// the k best of each list.  A list that overflows raises a device flag and the launch of the old kernels
+// that follows - gated on that flag - recomputes the search (tested by forcing a tiny list).
+//
+//   TERMS == 3: q.x ~ qh.xh + ql.xh + qh.xl (as k_flat_l2_bf), candidate distances are final.
+//   TERMS == 1: q.x ~ qh.xh only (one third of the matrix work, half of the HBM bytes).  |q.x - qh.xh| <=
+//               (2^-8 + 2^-18) sum|q_i x_i| <= 2^-8 (1 + 2^-9) |q| |x| for round-to-nearest bf16 operands, so the
+//               filter admits everything within that rigorous margin of tau_q and k_scan_select re-computes
+//               the candidates' distances in exact fp32 from the fp32 rows before selecting.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float f) {  // finite inputs
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// rows [n][D] fp32 -> fragment-tiled bf16 planes: unit ((tile * NS + s) * 2 + half) * 32 + r holds dims
+// 16 s + 8 half + [0, 8) of row 32 tile + r (the 32x32x16 A / B operand of lane 32 half + r).  hi = rne(x),
+// lo = rne(x - hi) (x - hi is exact).  Optional per-row half norms (0.5 |x|^2, +inf for rows >= n) and per-tile
+// max |x| (over valid rows).  Tiles [first_tile, first_tile + gridDim.x).
+template <int D>
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, long long n, long long first_tile,
+                                                      const float* __restrict__ norms, u32x4k* __restrict__ hi,
+                                                      u32x4k* __restrict__ lo, float* __restrict__ hnorm,
+                                                      float* __restrict__ tmax) {
+  constexpr int NS = D / 16, PU = NS * 64;
+  const long long tile = first_tile + blockIdx.x;
+  for (int o = threadIdx.x; o < PU; o += 256) {
+    const int s = o >> 6, h = (o >> 5) & 1, r = o & 31;
+    const long long row = tile * 32 + r;
+    float v[8];
+    if (row < n) {
+      const float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * D + 16 * s + 8 * h);
+      const float4 b = *reinterpret_cast<const float4*>(x + (size_t)row * D + 16 * s + 8 * h + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    unsigned hb[8], lb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      hb[j] = bf16_rne_bits(v[j]);
+      lb[j] = bf16_rne_bits(v[j] - __uint_as_float(hb[j] << 16));
+    }
+    hi[(size_t)tile * PU + o] = u32x4k{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
+    if (lo) lo[(size_t)tile * PU + o] = u32x4k{lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16)};
+  }
+  if (hnorm && threadIdx.x < 64) {
+    const int r = threadIdx.x & 31;
+    const long long row = tile * 32 + r;
+    const float nn = row < n ? norms[row] : 0.f;
+    if (threadIdx.x < 32) hnorm[tile * 32 + r] = row < n ? 0.5f * nn : __builtin_inff();
+    float m = sqrtf(nn);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (threadIdx.x == 0) tmax[tile] = m;
+  }
+}
+
+struct ScanArgs {
+  const u32x4k* xh;      // [ntiles][NS*64] units
+  const u32x4k* xl;      // TERMS == 3
+  const float* hnorm;    // [ntiles*32] 0.5 |x|^2, +inf beyond n
+  const float* tmax;     // [ntiles] max |x| of the tile's valid rows
+  const u32x4k* qh;      // [nqt][NS*64]
+  const u32x4k* ql;
+  const float* qnorm;    // [nq]
+  const float* tau;      // sample search result [nq][tau_k]; the bound is its last column
+  int tau_k;
+  long long n, ntiles;
+  int nq, nqt;
+  float* cand_d;         // [nq][cap]
+  int* cand_i;           // [nq][cap] row ids
+  int* cnt;              // [nq]
+  int cap;
+};
+
+// NW waves per workgroup, each owning one 32-row tile (tile = wt * NW + wave); workgroups walk the WG tiles grid-stride.
+template <int D, int TERMS, int NW>
+__global__ __launch_bounds__(NW * 64) void k_l2_scan(ScanArgs a) {
+  constexpr int NS = D / 16, PU = NS * 64;          // steps; 16-B units per tile and plane
+  constexpr int QBUF_U = PU * (TERMS == 3 ? 2 : 1);  // one staged query tile: [hi plane | lo plane]
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  u32x4k* qbuf = reinterpret_cast<u32x4k*>(dyn_smem);                       // [2][QBUF_U]
+  float* s_hc = reinterpret_cast<float*>(dyn_smem + (size_t)2 * QBUF_U * 16);  // [nqt*32] 0.5 (|q|^2 - tau')
+  float* s_sq = s_hc + a.nqt * 32;                                            // [nqt*32] 2^-8-scaled |q| (TERMS == 1)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+
+  for (int q = tid; q < a.nqt * 32; q += NW * 64) {
+    float hc = __builtin_inff(), sq = 0.f;
+    if (q < a.nq) {
+      const float t = a.tau[(size_t)q * a.tau_k + (a.tau_k - 1)];
+      const float qn = a.qnorm[q];
+      // slack: the sample's distances come from another kernel (other rounding of the same products)
+      hc = 0.5f * (qn - (t + 2e-5f * (1.0f + t)));
+      sq = 0.00390625f * 1.002f * sqrtf(qn);  // 2^-8 (1 + 2^-9) |q|, rounded up
+    }
+    s_hc[q] = hc;
+    if (TERMS == 1) s_sq[q] = sq;
+  }
+
+  const long long nwt = (a.ntiles + NW - 1) / NW;
+  auto stage_q = [&](int qt, int buf) {
+#pragma unroll
+    for (int u = wave * 64; u < PU; u += NW * 64) {  // wave-uniform LDS base, lane-linear 1 KiB pieces
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(a.qh + (size_t)qt * PU + u + lane),
+                                       (lds_void_t*)(qbuf + (size_t)buf * QBUF_U + u), 16, 0, 0);
+      if (TERMS == 3)
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(a.ql + (size_t)qt * PU + u + lane),
+                                         (lds_void_t*)(qbuf + (size_t)buf * QBUF_U + PU + u), 16, 0, 0);
+    }
+  };
+
+  u32x4k xh[NS], xl[TERMS == 3 ? NS : 1];
+  float4 hx[4];  // 0.5 |x|^2 of rows 8 g + 4 half + {0..3}
+  float sxm = 0.f;
+  long long wt = blockIdx.x;
+  auto tile_of = [&](long long w) {
+    const long long t = w * NW + wave;
+    return t < a.ntiles ? t : a.ntiles - 1;  // clamped duplicates are masked through row0 below
+  };
+  if (wt < nwt) {
+    const long long t = tile_of(wt);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      xh[s] = a.xh[(size_t)t * PU + s * 64 + lane];
+      if (TERMS == 3) xl[s] = a.xl[(size_t)t * PU + s * 64 + lane];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) hx[g] = *reinterpret_cast<const float4*>(a.hnorm + t * 32 + 8 * g + 4 * half);
+    sxm = a.tmax[t];
+    stage_q(0, 0);
+  }
+  int it = 0;  // staged query tiles so far: tile `it` lives in buffer it & 1
+  for (; wt < nwt; wt += gridDim.x) {
+    const bool own = wt * NW + wave < a.ntiles;  // a clamped duplicate tile appends nothing
+    const long long row0 = tile_of(wt) * 32;
+    const long long nwt_next = wt + gridDim.x;
+    const bool more_tiles = nwt_next < nwt;
+    const long long tn = more_tiles ? tile_of(nwt_next) : 0;
+    for (int qt = 0; qt < a.nqt; ++qt, ++it) {
+      const bool last_qt = qt == a.nqt - 1;
+      // the staged tile has landed (this wave's pieces: vmcnt; everyone's: barrier) and every wave is done
+      // reading the other buffer (program order before the barrier)
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+      __syncthreads();
+      if (!last_qt) stage_q(qt + 1, (it + 1) & 1);
+      else if (more_tiles) stage_q(0, (it + 1) & 1);
+      const u32x4k* qb = qbuf + (size_t)(it & 1) * QBUF_U;
+      const float hcq = s_hc[qt * 32 + col];
+      float thr_q = hcq;
+      if (TERMS == 1) thr_q = hcq - s_sq[qt * 32 + col] * sxm;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      // query fragments PF steps ahead of their MFMAs (a lone ds_read -> wait -> MFMA chain exposes the LDS latency)
+      constexpr int PF = 4;
+      u32x4k bh[PF], bl[TERMS == 3 ? PF : 1];
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        bh[s] = qb[s * 64 + lane];
+        if (TERMS == 3) bl[s] = qb[PU + s * 64 + lane];
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const bf16x8 ch = __builtin_bit_cast(bf16x8, bh[s % PF]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xh[s]), ch, acc, 0, 0, 0);
+        if (TERMS == 3) {
+          const bf16x8 cl = __builtin_bit_cast(bf16x8, bl[s % PF]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xl[s]), ch, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xh[s]), cl, acc, 0, 0, 0);
+        }
+        if (s + PF < NS) {
+          bh[s % PF] = qb[(s + PF) * 64 + lane];
+          if (TERMS == 3) bl[s % PF] = qb[PU + (s + PF) * 64 + lane];
+        }
+        if (last_qt && more_tiles) {  // the next row tile replaces this one in place, step by step
+          xh[s] = a.xh[(size_t)tn * PU + s * 64 + lane];
+          if (TERMS == 3) xl[s] = a.xl[(size_t)tn * PU + s * 64 + lane];
+        }
+      }
+      if (!last_qt) {  // pin the issue order of the steady-state body: PF reads ahead, then MFMAs and reads alternate
+        __builtin_amdgcn_sched_group_barrier(0x100, PF * (TERMS == 3 ? 2 : 1), 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          __builtin_amdgcn_sched_group_barrier(0x008, TERMS, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 2 : 1, 0);
+        }
+      }
+      // filter: dist <= tau'  <=>  acc >= 0.5 |x|^2 + 0.5 (|q|^2 - tau')   (minus the TERMS == 1 margin)
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float hxr = r & 2 ? (r & 1 ? hx[r >> 2].w : hx[r >> 2].z) : (r & 1 ? hx[r >> 2].y : hx[r >> 2].x);
+        any |= acc[r] >= hxr + thr_q;
+      }
+      if (any && own) {
+        const int qi = qt * 32 + col;
+        const float qn = a.qnorm[qi < a.nq ? qi : 0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float hxr = r & 2 ? (r & 1 ? hx[r >> 2].w : hx[r >> 2].z) : (r & 1 ? hx[r >> 2].y : hx[r >> 2].x);
+          if (acc[r] >= hxr + thr_q) {
+            float dist = (qn + 2.0f * hxr) - 2.0f * acc[r];
+            dist = dist < 0.f ? 0.f : dist;
+            const int pos = atomicAdd(a.cnt + qi, 1);
+            if (pos < a.cap) {
+              a.cand_d[(size_t)qi * a.cap + pos] = dist;
+              a.cand_i[(size_t)qi * a.cap + pos] = (int)(row0 + (r & 3) + 8 * (r >> 2) + 4 * half);
+            }
+          }
+        }
+      }
+      if (last_qt && more_tiles) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) hx[g] = *reinterpret_cast<const float4*>(a.hnorm + tn * 32 + 8 * g + 4 * half);
+        sxm = a.tmax[tn];
+      }
+    }
+  }
+}
+
+// One workgroup per query: (TERMS == 1: exact fp32 distances of the candidates,) then the k best by (dist, id).
+template <int D, int TERMS>
+__global__ __launch_bounds__(256) void k_scan_select(const float* __restrict__ db, const float* __restrict__ dbnorm,
+                                                     const float* __restrict__ q, const float* __restrict__ qnorm,
+                                                     const float* __restrict__ cand_d, const int* __restrict__ cand_i,
+                                                     const int* __restrict__ cnt, int cap, int k, float* __restrict__ Dout,
+                                                     long long* __restrict__ Iout, int* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  float* sd = reinterpret_cast<float*>(dyn_smem);  // [cap]
+  int* si = reinterpret_cast<int*>(sd + cap);      // [cap]
+  __shared__ float s_bv[4];
+  __shared__ int s_bi[4];
+  const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int c = cnt[qi];
+  if (c > cap) {
+    if (tid == 0) atomicOr(overflow, 1);
+    c = cap;
+  }
+  for (int j = tid; j < c; j += 256) si[j] = cand_i[(size_t)qi * cap + j];
+  if (TERMS == 3) {
+    for (int j = tid; j < c; j += 256) sd[j] = cand_d[(size_t)qi * cap + j];
+  } else {
+    // a half wave per candidate: lane l of 32 owns dims 4 l + 128 t + [0, 4)
+    constexpr int NV = D / 128;
+    const int l32 = lane & 31, hw = tid >> 5;
+    float4 qv[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) qv[t] = *reinterpret_cast<const float4*>(q + (size_t)qi * D + 128 * t + 4 * l32);
+    const float qn = qnorm[qi];
+    for (int j0 = hw; j0 < c; j0 += 16) {
+      const int j1 = j0 + 8;
+      const int r0 = cand_i[(size_t)qi * cap + j0];
+      const int r1 = cand_i[(size_t)qi * cap + (j1 < c ? j1 : j0)];
+      float4 x0[NV], x1[NV];
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        x0[t] = *reinterpret_cast<const float4*>(db + (size_t)r0 * D + 128 * t + 4 * l32);
+        x1[t] = *reinterpret_cast<const float4*>(db + (size_t)r1 * D + 128 * t + 4 * l32);
+      }
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        s0 = fmaf(qv[t].x, x0[t].x, s0); s0 = fmaf(qv[t].y, x0[t].y, s0);
+        s0 = fmaf(qv[t].z, x0[t].z, s0); s0 = fmaf(qv[t].w, x0[t].w, s0);
+        s1 = fmaf(qv[t].x, x1[t].x, s1); s1 = fmaf(qv[t].y, x1[t].y, s1);
+        s1 = fmaf(qv[t].z, x1[t].z, s1); s1 = fmaf(qv[t].w, x1[t].w, s1);
+      }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off, 64);
+        s1 += __shfl_xor(s1, off, 64);
+      }
+      if (l32 == 0) {
+        float d0 = (qn + dbnorm[r0]) - 2.0f * s0;
+        sd[j0] = d0 < 0.f ? 0.f : d0;
+        if (j1 < c) {
+          float d1 = (qn + dbnorm[r1]) - 2.0f * s1;
+          sd[j1] = d1 < 0.f ? 0.f : d1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float lv = -1.f;
+  int li = -1;  // last emitted (dist, id): distances are >= 0
+  for (int r = 0; r < k; ++r) {
+    float bv = FLT_MAX;
+    int bi = 0x7FFFFFFF;
+    for (int j = tid; j < c; j += 256) {
+      const float v = sd[j];
+      const int i = si[j];
+      const bool after = v > lv || (v == lv && i > li);
+      if (after && (v < bv || (v == bv && i < bi))) {
+        bv = v;
+        bi = i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov < bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      s_bv[wave] = bv;
+      s_bi[wave] = bi;
+    }
+    __syncthreads();
+    bv = s_bv[0];
+    bi = s_bi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (s_bv[w] < bv || (s_bv[w] == bv && s_bi[w] < bi)) {
+        bv = s_bv[w];
+        bi = s_bi[w];
+      }
+    __syncthreads();
+    if (tid == 0) {
+      Dout[(size_t)qi * k + r] = bi == 0x7FFFFFFF ? FLT_MAX : bv;
+      Iout[(size_t)qi * k + r] = bi == 0x7FFFFFFF ? -1 : (long long)bi;
+    }
+    lv = bv;
+    li = bi;
+    if (bi == 0x7FFFFFFF) lv = FLT_MAX;  // exhausted: the remaining rounds emit padding
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -597,6 +962,27 @@ struct eioku_index {
   int* pi = nullptr; size_t picap = 0;
   float* dout = nullptr; size_t dcap = 0;
   long long* iout = nullptr; size_t icap = 0;
+  // scan path (see k_l2_scan): fragment-tiled bf16 planes of the rows, built lazily and extended on add()
+  unsigned char* xh = nullptr; size_t xhcap = 0;
+  unsigned char* xl = nullptr; size_t xlcap = 0;
+  float* hnorm = nullptr; size_t hncap = 0;
+  float* tmax = nullptr; size_t tmcap = 0;
+  long long planes_n = 0;      // rows covered by the planes
+  bool planes_lo = false;      // lo plane present
+  unsigned char* qh = nullptr; size_t qhcap = 0;
+  unsigned char* ql = nullptr; size_t qlcap = 0;
+  float* tau = nullptr; size_t taucap = 0;
+  long long* tau_i = nullptr; size_t tauicap = 0;
+  float* cand_d = nullptr; size_t cdcap = 0;
+  int* cand_i = nullptr; size_t cicap = 0;
+  int* cnt = nullptr; size_t cntcap = 0;  // [nq] counters + 1 overflow word
+  // parameters (eioku_index_set_param)
+  int scan_mode = 2;           // 0: off; 1: three-term products; 2: one-term filter + exact fp32 re-rank
+  int scan_cap = 8192;         // candidate slots per query
+  long long scan_min_rows = 262144;
+  long long scan_sample = 0;   // sample rows for the bound (0: automatic)
+  int scan_waves = 0;          // waves per scan workgroup (0: automatic)
+  int last_overflow_checked = 0;
 };
 
 namespace {
@@ -672,7 +1058,8 @@ void eioku_index_destroy(eioku_index* ix) {
   if (!ix) return;
   (void)hipDeviceSynchronize();
   if (ix->x && !ix->attached) (void)hipFree(ix->x);
-  void* bufs[] = {ix->norms, ix->qbuf, ix->qnorm, ix->pd, ix->pi, ix->dout, ix->iout};
+  void* bufs[] = {ix->norms, ix->qbuf, ix->qnorm, ix->pd, ix->pi, ix->dout, ix->iout, ix->xh, ix->xl, ix->hnorm,
+                  ix->tmax, ix->qh, ix->ql, ix->tau, ix->tau_i, ix->cand_d, ix->cand_i, ix->cnt};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete ix;
@@ -688,6 +1075,7 @@ int eioku_index_reset(eioku_index* ix) {
     ix->cap = 0;
   }
   ix->n = 0;
+  ix->planes_n = 0;
   return EIOKU_OK;
 }
 
@@ -702,15 +1090,25 @@ int eioku_index_add(eioku_index* ix, const float* x, long long n, int mem, void*
   if (need > ix->cap) {
     long long ncap = ix->cap ? ix->cap : 1024;
     while (ncap < need) ncap *= 2;
+    // Earlier add() calls queued their copy + norms kernel on the caller's stream, which may be a
+    // non-blocking one the NULL stream does not wait for: move the old rows ON that stream and drain it
+    // before the old buffers are freed (a blocking hipMemcpy here could read rows that have not landed).
     float* nx = nullptr;
-    EIOKU_HIP_CHECK(hipMalloc((void**)&nx, (size_t)ncap * ix->d * sizeof(float)));
-    if (ix->n) EIOKU_HIP_CHECK(hipMemcpy(nx, ix->x, (size_t)ix->n * ix->d * sizeof(float), hipMemcpyDeviceToDevice));
-    if (ix->x) (void)hipFree(ix->x);
-    ix->x = nx;
     float* nn = nullptr;
-    EIOKU_HIP_CHECK(hipMalloc((void**)&nn, (size_t)ncap * sizeof(float)));
-    if (ix->n) EIOKU_HIP_CHECK(hipMemcpy(nn, ix->norms, (size_t)ix->n * sizeof(float), hipMemcpyDeviceToDevice));
+    EIOKU_HIP_CHECK(hipMalloc((void**)&nx, (size_t)ncap * ix->d * sizeof(float)));
+    if (hipMalloc((void**)&nn, (size_t)ncap * sizeof(float)) != hipSuccess) {
+      (void)hipFree(nx);
+      set_error("hipMalloc of %lld norms failed", ncap);
+      return EIOKU_ENOMEM;
+    }
+    if (ix->n) {
+      EIOKU_HIP_CHECK(hipMemcpyAsync(nx, ix->x, (size_t)ix->n * ix->d * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      EIOKU_HIP_CHECK(hipMemcpyAsync(nn, ix->norms, (size_t)ix->n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
+    if (ix->x) (void)hipFree(ix->x);
     if (ix->norms) (void)hipFree(ix->norms);
+    ix->x = nx;
     ix->norms = nn;
     ix->norms_cap = ncap;
     ix->cap = ncap;
@@ -734,6 +1132,7 @@ int eioku_index_attach(eioku_index* ix, float* x_dev, long long n, void* stream_
   ix->attached = true;
   ix->n = n;
   ix->cap = n;
+  ix->planes_n = 0;  // rebuilt by the next wide search
   if (ix->norms_cap < n) {
     if (ix->norms) (void)hipFree(ix->norms);
     ix->norms = nullptr;
@@ -743,15 +1142,15 @@ int eioku_index_attach(eioku_index* ix, float* x_dev, long long n, void* stream_
   return norms_for(x_dev, n, ix->d, ix->norms, (hipStream_t)stream_);
 }
 
-int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D, int64_t* I, int mem,
-                       void* stream_) {
-  EIOKU_REQUIRE_INIT();
-  EIOKU_REQUIRE(ix && nq >= 0 && k >= 1, "bad argument");
-  EIOKU_REQUIRE(k <= 32, "k=%d not supported (k <= 32)", k);
-  EIOKU_REQUIRE(mem == EIOKU_MEM_HOST || mem == EIOKU_MEM_DEVICE, "bad mem flag %d", mem);
-  if (nq == 0) return EIOKU_OK;
-  EIOKU_REQUIRE(q && D && I, "NULL buffer");
-  hipStream_t stream = (hipStream_t)stream_;
+}  // extern "C"
+
+namespace {
+
+// The register-tile kernels (k_flat_l2 / k_flat_l2_bf) + k_topk_merge over rows of the index: a full search
+// (sample_slabs == 0) or an exact search of `sample_slabs` strided slabs of `sample_rows` rows each (the scan
+// path's bound).  All pointers are device pointers.  gate (optional): device word, the launches are no-ops when 0.
+int legacy_search(eioku_index* ix, const float* dq, int nq, int k, const float* lbd, const long long* lbi, float* dD,
+                  long long* dI, const int* gate, int sample_slabs, long long sample_rows, bool prof, hipStream_t stream) {
   const int d = ix->d;
   const int K = k == 1 ? 1 : (k <= 16 ? 16 : 32);  // k == 1: coarse assignment (k-means / IVF), a single compare per row
   const int qtiles = (nq + kQT - 1) / kQT;
@@ -760,45 +1159,29 @@ int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D,
   // wide pass with half of its waves idle (11.4 ms)
   const bool wide = qtiles > 2;
   const int ygroups = wide ? (qtiles + kWaves - 1) / kWaves : qtiles;
-  // One workgroup is resident per CU (the query tile fills the register file), and a slab that is too
-  // short never leaves the phase where most rows still enter some lane's top-K (the insertion path runs
-  // whenever ANY lane of the wave inserts): ~2 workgroups per CU over the whole grid.
-  long long want = (long long)num_cus() * 2 / ygroups;
-  if (want < 1) want = 1;
-  long long rpb = (ix->n + want - 1) / want;
-  rpb = ((rpb + kRT * kWaves - 1) / (kRT * kWaves)) * (kRT * kWaves);
-  if (rpb < kRT * kWaves) rpb = kRT * kWaves;
-  const long long slabs = ix->n ? (ix->n + rpb - 1) / rpb : 1;
-  EIOKU_REQUIRE(rpb < (1ll << 31), "slab too large");
-
-  int rc;
-  const float* dq = q;
-  if (mem == EIOKU_MEM_HOST) {
-    rc = grow(&ix->qbuf, &ix->qcap, (size_t)nq * d * sizeof(float));
-    if (rc) return rc;
-    EIOKU_HIP_CHECK(hipMemcpyAsync(ix->qbuf, q, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, stream));
-    dq = ix->qbuf;
+  long long rpb, slabs, stride;
+  if (sample_slabs > 0) {
+    rpb = sample_rows;
+    slabs = sample_slabs;
+    stride = ix->n / sample_slabs;
+  } else {
+    // One workgroup is resident per CU (the query tile fills the register file), and a slab that is too
+    // short never leaves the phase where most rows still enter some lane's top-K (the insertion path runs
+    // whenever ANY lane of the wave inserts): ~2 workgroups per CU over the whole grid.
+    long long want = (long long)num_cus() * 2 / ygroups;
+    if (want < 1) want = 1;
+    rpb = (ix->n + want - 1) / want;
+    rpb = ((rpb + kRT * kWaves - 1) / (kRT * kWaves)) * (kRT * kWaves);
+    if (rpb < kRT * kWaves) rpb = kRT * kWaves;
+    slabs = ix->n ? (ix->n + rpb - 1) / rpb : 1;
+    stride = rpb;
   }
-  EIOKU_REQUIRE(((uintptr_t)dq & 15) == 0, "queries must be 16-byte aligned");
-  rc = grow(&ix->qnorm, &ix->qncap, (size_t)nq * sizeof(float));
-  if (rc) return rc;
-  rc = norms_for(dq, nq, d, ix->qnorm, stream);
-  if (rc) return rc;
+  EIOKU_REQUIRE(rpb < (1ll << 31), "slab too large");
   const size_t pn = (size_t)ygroups * (wide ? kWaves : 1) * slabs * kQT * K;
-  rc = grow(&ix->pd, &ix->pdcap, pn * sizeof(float));
+  int rc = grow(&ix->pd, &ix->pdcap, pn * sizeof(float));
   if (rc) return rc;
   rc = grow(&ix->pi, &ix->picap, pn * sizeof(int));
   if (rc) return rc;
-  float* dD = D;
-  long long* dI = (long long*)I;
-  if (mem == EIOKU_MEM_HOST) {
-    rc = grow(&ix->dout, &ix->dcap, (size_t)nq * k * sizeof(float));
-    if (rc) return rc;
-    rc = grow(&ix->iout, &ix->icap, (size_t)nq * k * sizeof(long long));
-    if (rc) return rc;
-    dD = ix->dout;
-    dI = ix->iout;
-  }
   KnnArgs a;
   a.db = ix->x;
   a.dbnorm = ix->norms;
@@ -811,32 +1194,336 @@ int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D,
   a.pd = ix->pd;
   a.pi = ix->pi;
   a.id_base = 0;
+  a.lbd = lbd;
+  a.lbi = lbi;
+  a.slab_stride = stride;
+  a.gate = gate;
   dim3 grid((unsigned)slabs, (unsigned)ygroups);
-  prof_start(EIOKU_PROF_KNN, stream);
-  // wide searches (nq > 64) with k <= 16 over d in {128, 256, 384}: split-bf16 kernel (see k_flat_l2_bf)
+  if (prof) prof_start(EIOKU_PROF_KNN, stream);
+  // wide searches (nq > 64) with k <= 16 over d in {128, 256, 384}: split-bf16 kernel (see k_flat_l2_bf); a bounded
+  // search (lbd) stays on the exact-fp32 kernels so that successive rounds see bit-identical distances
   static const bool bf_off = getenv("EIOKU_KNN_BF16") && atoi(getenv("EIOKU_KNN_BF16")) == 0;
   rc = -1;
-  if (wide && K == 16 && !bf_off) rc = launch_search_bf<16>(d, a, grid, stream);
+  if (wide && K == 16 && !bf_off && !lbd) rc = launch_search_bf<16>(d, a, grid, stream);
   if (rc != -1) {
   } else if (K == 1) rc = wide ? launch_search_k<1, true>(d, a, grid, stream) : launch_search_k<1, false>(d, a, grid, stream);
   else if (wide) rc = K == 16 ? launch_search_k<16, true>(d, a, grid, stream) : launch_search_k<32, true>(d, a, grid, stream);
   else rc = K == 16 ? launch_search_k<16, false>(d, a, grid, stream) : launch_search_k<32, false>(d, a, grid, stream);
-  prof_stop(EIOKU_PROF_KNN, stream);
+  if (prof) prof_stop(EIOKU_PROF_KNN, stream);
   if (rc) return rc;
   if (K == 1)
     hipLaunchKernelGGL((k_topk_merge<1>), dim3(nq), dim3(64), 0, stream, ix->pd, ix->pi, (const long long*)nullptr,
-                       (int)slabs, nq, K, 1, (const long long*)nullptr, rpb, k, dD, dI);
+                       (int)slabs, nq, K, 1, (const long long*)nullptr, stride, k, dD, dI, gate);
   else if (K == 16)
     hipLaunchKernelGGL((k_topk_merge<16>), dim3(nq), dim3(64), 0, stream, ix->pd, ix->pi, (const long long*)nullptr,
-                       (int)slabs, nq, K, 1, (const long long*)nullptr, rpb, k, dD, dI);
+                       (int)slabs, nq, K, 1, (const long long*)nullptr, stride, k, dD, dI, gate);
   else
     hipLaunchKernelGGL((k_topk_merge<32>), dim3(nq), dim3(64), 0, stream, ix->pd, ix->pi, (const long long*)nullptr,
-                       (int)slabs, nq, K, 1, (const long long*)nullptr, rpb, k, dD, dI);
+                       (int)slabs, nq, K, 1, (const long long*)nullptr, stride, k, dD, dI, gate);
   EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+template <int D>
+int launch_split(const float* x, long long n, long long first_tile, long long tiles, const float* norms, void* hi,
+                 void* lo, float* hnorm, float* tmax, hipStream_t stream) {
+  if (tiles <= 0) return EIOKU_OK;
+  hipLaunchKernelGGL((k_split_planes<D>), dim3((unsigned)tiles), dim3(256), 0, stream, x, n, first_tile, norms,
+                     (u32x4k*)hi, (u32x4k*)lo, hnorm, tmax);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+int split_planes(int d, const float* x, long long n, long long first_tile, long long tiles, const float* norms,
+                 void* hi, void* lo, float* hnorm, float* tmax, hipStream_t stream) {
+  switch (d) {
+    case 128: return launch_split<128>(x, n, first_tile, tiles, norms, hi, lo, hnorm, tmax, stream);
+    case 256: return launch_split<256>(x, n, first_tile, tiles, norms, hi, lo, hnorm, tmax, stream);
+    case 384: return launch_split<384>(x, n, first_tile, tiles, norms, hi, lo, hnorm, tmax, stream);
+  }
+  set_error("scan path: dimension %d not supported", d);
+  return EIOKU_EINVAL;
+}
+
+// a buffer that keeps its contents when it grows (the planes are extended on add())
+template <typename T>
+int grow_keep(T** p, size_t* cap, size_t bytes, size_t keep, hipStream_t stream) {
+  if (*cap >= bytes) return EIOKU_OK;
+  size_t want = *cap ? *cap : bytes;
+  while (want < bytes) want += want / 2 + 1;
+  T* np = nullptr;
+  EIOKU_HIP_CHECK(hipMalloc((void**)&np, want));
+  if (*p) {
+    if (keep) EIOKU_HIP_CHECK(hipMemcpyAsync(np, *p, keep, hipMemcpyDeviceToDevice, stream));
+    EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
+    (void)hipDeviceSynchronize();
+    (void)hipFree(*p);
+  }
+  *p = np;
+  *cap = want;
+  return EIOKU_OK;
+}
+
+int ensure_planes(eioku_index* ix, bool need_lo, hipStream_t stream) {
+  const int d = ix->d;
+  const size_t tile_b = (size_t)d * 32 * 2;  // bytes per 32-row tile and plane
+  const long long ntiles = (ix->n + 31) / 32;
+  if (need_lo && !ix->planes_lo) ix->planes_n = 0;  // the lo plane was never built: start over
+  const long long keep_tiles = ix->planes_n / 32;    // complete tiles stay valid
+  int rc = grow_keep(&ix->xh, &ix->xhcap, (size_t)ntiles * tile_b, (size_t)keep_tiles * tile_b, stream);
+  if (rc) return rc;
+  if (need_lo || ix->planes_lo) {
+    rc = grow_keep(&ix->xl, &ix->xlcap, (size_t)ntiles * tile_b, (size_t)keep_tiles * tile_b, stream);
+    if (rc) return rc;
+  }
+  rc = grow_keep(&ix->hnorm, &ix->hncap, (size_t)ntiles * 32 * sizeof(float), (size_t)keep_tiles * 32 * sizeof(float), stream);
+  if (rc) return rc;
+  rc = grow_keep(&ix->tmax, &ix->tmcap, (size_t)ntiles * sizeof(float), (size_t)keep_tiles * sizeof(float), stream);
+  if (rc) return rc;
+  if (ix->planes_n != ix->n) {
+    const bool lo = need_lo || ix->planes_lo;
+    rc = split_planes(d, ix->x, ix->n, keep_tiles, ntiles - keep_tiles, ix->norms, ix->xh, lo ? ix->xl : nullptr,
+                      ix->hnorm, ix->tmax, stream);
+    if (rc) return rc;
+    ix->planes_lo = lo;
+    ix->planes_n = ix->n;
+  }
+  return EIOKU_OK;
+}
+
+template <int D, int TERMS>
+int launch_scan(const eioku_index* ix, const ScanArgs& a, int nw, hipStream_t stream) {
+  constexpr int PU = (D / 16) * 64;
+  const size_t lds = (size_t)2 * PU * (TERMS == 3 ? 2 : 1) * 16 + (size_t)a.nqt * 32 * 4 * 2;
+  const long long nwt = (a.ntiles + nw - 1) / nw;
+  // co-resident workgroups per CU: LDS (160 KiB) and 2048 threads
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 2048 / (nw * 64)) per_cu = 2048 / (nw * 64);
+  if (per_cu < 1) per_cu = 1;
+  if (TERMS == 3 && per_cu > 1) per_cu = 1;  // the 3-term kernel holds 192 operand registers: one wave per SIMD
+  long long grid = (long long)num_cus() * per_cu;
+  if (grid > nwt) grid = nwt;
+#define EIOKU_SCAN_LAUNCH(NW_)                                                                              \
+  do {                                                                                                      \
+    EIOKU_HIP_CHECK(hipFuncSetAttribute((const void*)k_l2_scan<D, TERMS, NW_>,                              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+    hipLaunchKernelGGL((k_l2_scan<D, TERMS, NW_>), dim3((unsigned)grid), dim3(NW_ * 64), lds, stream, a);   \
+  } while (0)
+  if (nw == 4) EIOKU_SCAN_LAUNCH(4);
+  else if (nw == 8) EIOKU_SCAN_LAUNCH(8);
+  else {
+    set_error("scan_waves must be 4 or 8");
+    return EIOKU_EINVAL;
+  }
+#undef EIOKU_SCAN_LAUNCH
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+template <int D, int TERMS>
+int launch_select(const eioku_index* ix, const float* dq, int nq, int cap, int k, float* dD, long long* dI, int* overflow,
+                  hipStream_t stream) {
+  const size_t lds = (size_t)cap * 8;
+  EIOKU_HIP_CHECK(hipFuncSetAttribute((const void*)k_scan_select<D, TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+  hipLaunchKernelGGL((k_scan_select<D, TERMS>), dim3(nq), dim3(256), lds, stream, ix->x, ix->norms, dq, ix->qnorm,
+                     ix->cand_d, ix->cand_i, ix->cnt, cap, k, dD, dI, overflow);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+// nq <= 1024 device queries through the scan path; qnorm already holds their norms
+int scan_search(eioku_index* ix, const float* dq, int nq, int k, float* dD, long long* dI, hipStream_t stream) {
+  const int d = ix->d;
+  const int terms = ix->scan_mode == 1 ? 3 : 1;
+  int rc = ensure_planes(ix, terms == 3, stream);
+  if (rc) return rc;
+  const int nqt = (nq + 31) / 32;
+  const size_t qplane = (size_t)nqt * d * 32 * 2;
+  rc = grow(&ix->qh, &ix->qhcap, qplane);
+  if (rc) return rc;
+  rc = grow(&ix->ql, &ix->qlcap, qplane);
+  if (rc) return rc;
+  rc = grow(&ix->tau, &ix->taucap, (size_t)nq * k * sizeof(float));
+  if (rc) return rc;
+  rc = grow(&ix->tau_i, &ix->tauicap, (size_t)nq * k * sizeof(long long));
+  if (rc) return rc;
+  const int cap = ix->scan_cap;
+  rc = grow(&ix->cand_d, &ix->cdcap, (size_t)nq * cap * sizeof(float));
+  if (rc) return rc;
+  rc = grow(&ix->cand_i, &ix->cicap, (size_t)nq * cap * sizeof(int));
+  if (rc) return rc;
+  rc = grow(&ix->cnt, &ix->cntcap, ((size_t)nq + 1) * sizeof(int));
+  if (rc) return rc;
+  int* overflow = ix->cnt + nq;
+  EIOKU_HIP_CHECK(hipMemsetAsync(ix->cnt, 0, ((size_t)nq + 1) * sizeof(int), stream));
+  rc = split_planes(d, dq, nq, 0, nqt, nullptr, ix->qh, terms == 3 ? ix->ql : nullptr, nullptr, nullptr, stream);
+  if (rc) return rc;
+  // bound: exact search of a strided sample (k-th best of a subset >= k-th best of the whole)
+  long long sample = ix->scan_sample > 0 ? ix->scan_sample : ix->n / 128;
+  if (sample < 32768) sample = 32768;
+  if (sample > 262144) sample = 262144;
+  const long long srows = 512;
+  int sslabs = (int)(sample / srows);
+  if ((long long)sslabs * srows * 2 > ix->n) sslabs = (int)(ix->n / (2 * srows));
+  rc = legacy_search(ix, dq, nq, k, nullptr, nullptr, ix->tau, ix->tau_i, nullptr, sslabs, srows, false, stream);
+  if (rc) return rc;
+  ScanArgs a;
+  a.xh = (const u32x4k*)ix->xh;
+  a.xl = (const u32x4k*)ix->xl;
+  a.hnorm = ix->hnorm;
+  a.tmax = ix->tmax;
+  a.qh = (const u32x4k*)ix->qh;
+  a.ql = (const u32x4k*)ix->ql;
+  a.qnorm = ix->qnorm;
+  a.tau = ix->tau;
+  a.tau_k = k;
+  a.n = ix->n;
+  a.ntiles = (ix->n + 31) / 32;
+  a.nq = nq;
+  a.nqt = nqt;
+  a.cand_d = ix->cand_d;
+  a.cand_i = ix->cand_i;
+  a.cnt = ix->cnt;
+  a.cap = cap;
+  const int nw = ix->scan_waves ? ix->scan_waves : (terms == 3 ? 4 : 8);
+  prof_start(EIOKU_PROF_KNN, stream);
+  rc = -1;
+#define EIOKU_SCAN_CASE(D_)                                                                    \
+  case D_:                                                                                     \
+    rc = terms == 3 ? launch_scan<D_, 3>(ix, a, nw, stream) : launch_scan<D_, 1>(ix, a, nw, stream); \
+    break;
+  switch (d) {
+    EIOKU_SCAN_CASE(128)
+    EIOKU_SCAN_CASE(256)
+    EIOKU_SCAN_CASE(384)
+  }
+#undef EIOKU_SCAN_CASE
+  prof_stop(EIOKU_PROF_KNN, stream);
+  if (rc) return rc;
+#define EIOKU_SEL_CASE(D_)                                                                                  \
+  case D_:                                                                                                  \
+    rc = terms == 3 ? launch_select<D_, 3>(ix, dq, nq, cap, k, dD, dI, overflow, stream)                    \
+                    : launch_select<D_, 1>(ix, dq, nq, cap, k, dD, dI, overflow, stream);                   \
+    break;
+  switch (d) {
+    EIOKU_SEL_CASE(128)
+    EIOKU_SEL_CASE(256)
+    EIOKU_SEL_CASE(384)
+  }
+#undef EIOKU_SEL_CASE
+  if (rc) return rc;
+  // a candidate list overflowed (adversarial data for the sample bound): the gated register-tile search redoes it
+  return legacy_search(ix, dq, nq, k, nullptr, nullptr, dD, dI, overflow, 0, 0, false, stream);
+}
+
+int search_impl(eioku_index* ix, const float* q, int nq, int k, const float* lbD, const int64_t* lbI, float* D,
+                int64_t* I, int mem, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(ix && nq >= 0 && k >= 1, "bad argument");
+  EIOKU_REQUIRE(k <= 32, "k=%d not supported (k <= 32)", k);
+  EIOKU_REQUIRE(mem == EIOKU_MEM_HOST || mem == EIOKU_MEM_DEVICE, "bad mem flag %d", mem);
+  EIOKU_REQUIRE((lbD == nullptr) == (lbI == nullptr), "lower bound needs both distances and ids");
+  if (nq == 0) return EIOKU_OK;
+  EIOKU_REQUIRE(q && D && I, "NULL buffer");
+  EIOKU_REQUIRE(ix->n < (1ll << 31), "index too large");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int d = ix->d;
+  int rc;
+  const float* dq = q;
+  const float* dlbD = lbD;
+  const long long* dlbI = (const long long*)lbI;
+  if (mem == EIOKU_MEM_HOST) {
+    const size_t qb = (((size_t)nq * d * sizeof(float)) + 255) & ~(size_t)255;
+    const size_t lb = lbD ? (size_t)nq * (sizeof(float) + sizeof(long long)) + 256 : 0;
+    rc = grow(&ix->qbuf, &ix->qcap, qb + lb);
+    if (rc) return rc;
+    EIOKU_HIP_CHECK(hipMemcpyAsync(ix->qbuf, q, (size_t)nq * d * sizeof(float), hipMemcpyHostToDevice, stream));
+    dq = ix->qbuf;
+    if (lbD) {
+      long long* li = (long long*)((unsigned char*)ix->qbuf + qb);
+      float* ld = (float*)(li + nq);
+      EIOKU_HIP_CHECK(hipMemcpyAsync(li, lbI, (size_t)nq * sizeof(long long), hipMemcpyHostToDevice, stream));
+      EIOKU_HIP_CHECK(hipMemcpyAsync(ld, lbD, (size_t)nq * sizeof(float), hipMemcpyHostToDevice, stream));
+      dlbD = ld;
+      dlbI = li;
+    }
+  }
+  EIOKU_REQUIRE(((uintptr_t)dq & 15) == 0, "queries must be 16-byte aligned");
+  rc = grow(&ix->qnorm, &ix->qncap, (size_t)nq * sizeof(float));
+  if (rc) return rc;
+  rc = norms_for(dq, nq, d, ix->qnorm, stream);
+  if (rc) return rc;
+  float* dD = D;
+  long long* dI = (long long*)I;
+  if (mem == EIOKU_MEM_HOST) {
+    rc = grow(&ix->dout, &ix->dcap, (size_t)nq * k * sizeof(float));
+    if (rc) return rc;
+    rc = grow(&ix->iout, &ix->icap, (size_t)nq * k * sizeof(long long));
+    if (rc) return rc;
+    dD = ix->dout;
+    dI = ix->iout;
+  }
+  const bool scan = ix->scan_mode != 0 && !dlbD && nq > 64 && k >= 2 && k <= 16 && ix->n >= ix->scan_min_rows &&
+                    (d == 128 || d == 256 || d == 384);
+  if (scan) {
+    // groups of <= 1024 queries: their planes (<= 1.5 MB) stay in every XCD's L2 while the rows stream past
+    for (int q0 = 0; q0 < nq; q0 += 1024) {
+      const int g = nq - q0 < 1024 ? nq - q0 : 1024;
+      if (q0) {
+        rc = norms_for(dq + (size_t)q0 * d, g, d, ix->qnorm, stream);
+        if (rc) return rc;
+      }
+      rc = scan_search(ix, dq + (size_t)q0 * d, g, k, dD + (size_t)q0 * k, dI + (size_t)q0 * k, stream);
+      if (rc) return rc;
+    }
+  } else {
+    rc = legacy_search(ix, dq, nq, k, dlbD, dlbI, dD, dI, nullptr, 0, 0, true, stream);
+    if (rc) return rc;
+  }
   if (mem == EIOKU_MEM_HOST) {
     EIOKU_HIP_CHECK(hipMemcpyAsync(D, dD, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, stream));
     EIOKU_HIP_CHECK(hipMemcpyAsync(I, dI, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, stream));
     EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return EIOKU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eioku_index_search(eioku_index* ix, const float* q, int nq, int k, float* D, int64_t* I, int mem,
+                       void* stream_) {
+  return search_impl(ix, q, nq, k, nullptr, nullptr, D, I, mem, stream_);
+}
+
+int eioku_index_search_after(eioku_index* ix, const float* q, int nq, int k, const float* after_D,
+                             const int64_t* after_I, float* D, int64_t* I, int mem, void* stream_) {
+  EIOKU_REQUIRE(after_D && after_I, "NULL lower bound");
+  return search_impl(ix, q, nq, k, after_D, after_I, D, I, mem, stream_);
+}
+
+int eioku_index_set_param(eioku_index* ix, const char* name, long long value) {
+  EIOKU_REQUIRE(ix && name, "bad argument");
+  if (!strcmp(name, "scan_mode")) {
+    EIOKU_REQUIRE(value >= 0 && value <= 2, "scan_mode is 0 (off), 1 (three-term) or 2 (one-term + exact re-rank)");
+    ix->scan_mode = (int)value;
+  } else if (!strcmp(name, "scan_cap")) {
+    EIOKU_REQUIRE(value >= 16 && value <= 16384, "scan_cap must be in [16, 16384]");
+    ix->scan_cap = (int)value;
+  } else if (!strcmp(name, "scan_min_rows")) {
+    EIOKU_REQUIRE(value >= 4096, "scan_min_rows must be >= 4096");
+    ix->scan_min_rows = value;
+  } else if (!strcmp(name, "scan_sample")) {
+    EIOKU_REQUIRE(value >= 0, "scan_sample must be >= 0");
+    ix->scan_sample = value;
+  } else if (!strcmp(name, "scan_waves")) {
+    EIOKU_REQUIRE(value == 0 || value == 4 || value == 8, "scan_waves must be 0, 4 or 8");
+    ix->scan_waves = (int)value;
+  } else {
+    set_error("unknown index parameter '%s'", name);
+    return EIOKU_EINVAL;
   }
   return EIOKU_OK;
 }

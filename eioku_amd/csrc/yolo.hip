@@ -73,6 +73,9 @@ struct eioku_yolo {
   int32_t* flat = nullptr;
   size_t flat_cap = 0;
   int32_t* pass_host = nullptr;  // [4]: cnt1[3], N*A of that call
+  hipEvent_t pass_event = nullptr;  // recorded behind the copy into pass_host; the word is read only once it has fired
+  bool pass_pending = false;
+  long long pass_seen[2] = {0, 0};  // last completed {passed, total}: what the decision uses until newer history lands
   int deep_idx[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};  // op indices of cv2.l.0 / cv2.l.1
   Cand* cands = nullptr;  // dense [N][A] followed by keys [N][A]
   size_t cands_cap = 0;
@@ -374,6 +377,8 @@ int record_pass_rate(eioku_yolo* y, int n, int A, hipStream_t stream) {
   int32_t* dev = y->flat + (size_t)10 * n * A + 8;
   hipLaunchKernelGGL(k_pass_record, dim3(1), dim3(256), 0, stream, y->counts, n, n * A, dev);
   EIOKU_HIP_CHECK(hipMemcpyAsync(y->pass_host, dev, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  EIOKU_HIP_CHECK(hipEventRecord(y->pass_event, stream));
+  y->pass_pending = true;
   return EIOKU_OK;
 }
 
@@ -637,6 +642,7 @@ void eioku_yolo_destroy(eioku_yolo* y) {
   if (y->lvl) (void)hipFree(y->lvl);
   if (y->flat) (void)hipFree(y->flat);
   if (y->pass_host) (void)hipHostFree(y->pass_host);
+  if (y->pass_event) (void)hipEventDestroy(y->pass_event);
   if (y->cands) (void)hipFree(y->cands);
   if (y->counts) (void)hipFree(y->counts);
   if (y->dets) (void)hipFree(y->dets);
@@ -816,11 +822,18 @@ int eioku_yolo_detect(eioku_yolo* y, const uint8_t* bgr, int n, int h, int w, co
   if (deep) {
     if (!y->pass_host) {
       EIOKU_HIP_CHECK(hipHostMalloc((void**)&y->pass_host, 4 * sizeof(int32_t), hipHostMallocDefault));
-      y->pass_host[0] = y->pass_host[1] = y->pass_host[2] = 0;
-      y->pass_host[3] = 0;  // no history yet -> dense
+      EIOKU_HIP_CHECK(hipEventCreateWithFlags(&y->pass_event, hipEventDisableTiming));
+      y->pass_host[0] = y->pass_host[1] = y->pass_host[2] = y->pass_host[3] = 0;  // no history yet -> dense
     }
-    const volatile int32_t* ph = y->pass_host;
-    const long long passed = (long long)ph[0] + ph[1] + ph[2], total = ph[3];
+    // The pinned word is the target of the previous call's asynchronous copy: consume it only once the event behind
+    // that copy has fired (no copy can be in flight then: the next one is issued further down), otherwise keep
+    // deciding from the last history that did complete.  A 4-int read racing the copy could tear.
+    if (y->pass_pending && hipEventQuery(y->pass_event) == hipSuccess) {
+      y->pass_seen[0] = (long long)y->pass_host[0] + y->pass_host[1] + y->pass_host[2];
+      y->pass_seen[1] = y->pass_host[3];
+      y->pass_pending = false;
+    }
+    const long long passed = y->pass_seen[0], total = y->pass_seen[1];
     deep = total > 0 && (float)passed <= deep_frac * (float)total;
     int32_t* f = y->flat;
     int32_t* fcnt = f + (size_t)10 * n * Aq;

@@ -138,7 +138,9 @@ class Yolov8Detector:
         if seed is not None:
             state = W.random_state(variant, nc, seed)
         else:
-            state = W.load_state(path, variant, nc)
+            state, own = W.load_checkpoint(path, variant, nc)
+            if own is not None and len(own) == nc:
+                names = own  # result.names of THIS checkpoint (a custom-trained model), not the COCO table
         return cls(variant, nc, state, names)
 
     def _conv_table(self):

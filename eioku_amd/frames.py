@@ -6,7 +6,8 @@ The reference reads frames with ``cv2.VideoCapture(video_path)`` - ``get(CAP_PRO
 out to ffmpeg.  Video *decode* is outside this round's scope, so this module
 only provides the same small surface over what is available:
 
-  * ``cv2`` itself when the deployment image has it (the reference's container does);
+  * ``cv2`` itself when the deployment image has it (the reference's container does): BGR frames for the
+    detectors and the decoder's luma plane for the scene stage (``Cv2FrameSource.luma_planes``);
   * ``.npy`` raw clips ``(n,h,w,3)`` uint8 BGR, memory mapped, with an optional ``<file>.json``
     sidecar ``{"fps": 29.97, "time_base": [1001, 30000], "duration": 6.673}``;
   * ``.y4m`` (YUV4MPEG2, 4:2:0 / 4:4:4 / mono, 8 bit) for the scene stage: exactly the luma plane the
@@ -20,6 +21,10 @@ from fractions import Fraction
 from pathlib import Path
 
 import numpy as np
+
+
+class EndOfStream(RuntimeError):
+    """A container's header promised more frames than its stream holds (CAP_PROP_FRAME_COUNT is an estimate)."""
 
 
 class FrameSource:
@@ -139,16 +144,42 @@ class Y4mSource(FrameSource):
         raise RuntimeError("y4m sources carry no BGR frames here; use them for scene detection")
 
 
+def bgr_to_luma_bt601(frames_bgr: np.ndarray) -> np.ndarray:
+    """OpenCV's 8-bit ``COLOR_BGR2YUV_I420`` luma (``RGB2YUV420p``: BT.601 studio range, 20-bit fixed
+    point, ``Y = (269484 R + 528482 G + 102760 B + (16 << 20) + (1 << 19)) >> 20``) [PUBLIC-LIB]."""
+    f = frames_bgr.astype(np.int64)
+    y = (269484 * f[..., 2] + 528482 * f[..., 1] + 102760 * f[..., 0] + (16 << 20) + (1 << 19)) >> 20
+    return y.astype(np.uint8)
+
+
 class Cv2FrameSource(FrameSource):
+    """``cv2.VideoCapture`` (what the reference opens, ``model_manager.py:237``).
+
+    ``luma_planes`` serves the scene stage, which in the reference is an ffmpeg child scoring the DECODER's
+    luma plane (``model_manager.py:736-755``).  A second capture of the same file is opened for it:
+
+    * with ``CAP_PROP_CONVERT_RGB = 0`` OpenCV's FFmpeg backend hands back the decoded frame without the
+      swscale BGR conversion - a single-channel ``(h, w)`` plane or a planar I420 ``(3h/2, w)`` image; the first
+      ``h`` rows are exactly the Y plane ffmpeg scores (bit-exact with the reference's scene score);
+    * a backend that ignores the property returns BGR; the luma is then recomputed with OpenCV's own
+      ``COLOR_BGR2YUV_I420`` integer formula.  YUV -> BGR -> Y does not round-trip exactly (+-1-2 codes on some
+      pixels), so the scene SCORE can differ from ffmpeg's in the last digits; cut decisions at the default
+      threshold (a 70-code mean difference) are far from that noise.  ``luma_exact`` says which case applies.
+    """
+
     def __init__(self, path):
         import cv2
 
         self._cv2 = cv2
+        self.path = path
         self.cap = cv2.VideoCapture(path)
         self.fps = self.cap.get(cv2.CAP_PROP_FPS) or 30
         self.total_frames = int(self.cap.get(cv2.CAP_PROP_FRAME_COUNT))
         self.time_base = _fps_to_time_base(self.fps)
         self.duration_s = self.total_frames / self.fps if self.fps else None
+        self._ycap = None
+        self._ypos = 0
+        self.luma_exact = None  # decided by the first luma frame
 
     def read(self):
         return self.cap.read()
@@ -158,9 +189,46 @@ class Cv2FrameSource(FrameSource):
 
     def release(self):
         self.cap.release()
+        if self._ycap is not None:
+            self._ycap.release()
+            self._ycap = None
+
+    def _luma_of(self, frame) -> np.ndarray:
+        f = np.asarray(frame)
+        if f.ndim == 2 or (f.ndim == 3 and f.shape[2] == 1):
+            f = f.reshape(f.shape[0], f.shape[1])
+            if self._h is None:
+                # (h, w) gray plane or (3h/2, w) planar 4:2:0: the capture's own frame height tells them apart
+                hh = int(self._ycap.get(self._cv2.CAP_PROP_FRAME_HEIGHT)) or f.shape[0]
+                self._h = hh if f.shape[0] in (hh, hh * 3 // 2) else f.shape[0]
+            self.luma_exact = True
+            return np.ascontiguousarray(f[: self._h])
+        self.luma_exact = False
+        return bgr_to_luma_bt601(f)
 
     def luma_planes(self, start, count):
-        raise RuntimeError("decoded BGR has no decoder luma; the scene stage needs a .y4m / raw source")
+        cv2 = self._cv2
+        if self._ycap is None or start < self._ypos:
+            if self._ycap is not None:
+                self._ycap.release()
+            self._ycap = cv2.VideoCapture(self.path)
+            self._ycap.set(cv2.CAP_PROP_CONVERT_RGB, 0)
+            self._ypos = 0
+            self._h = None
+        while self._ypos < start:  # sequential access is the only access a compressed stream offers
+            if not self._ycap.grab():
+                break
+            self._ypos += 1
+        out = []
+        for _ in range(count):
+            ok, frame = self._ycap.read()
+            if not ok:
+                break
+            self._ypos += 1
+            out.append(self._luma_of(frame))
+        if not out:
+            raise EndOfStream(f"{self.path!r}: no frame at index {start}")
+        return np.stack(out)
 
 
 def open_video(path: str) -> FrameSource:

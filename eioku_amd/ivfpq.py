@@ -163,7 +163,7 @@ class IndexIVFPQ:
         nq = q.shape[0]
         nprobe = min(self.nprobe, self.nlist)
         offsets, sizes, list_codes, list_ids = self._pack()
-        _, probes = self._quantizer.search(q, nprobe)
+        _, probes = self._quantizer.search_many(q, nprobe)  # nprobe > 32: chained rounds of 32 (search_after)
         probes = probes.contiguous()
         K = 16 if k <= 16 else 32
         pd = torch.empty((nprobe, nq, K), dtype=torch.float32, device=self.device)

@@ -269,14 +269,25 @@ class ModelManager:
                     scenes = [{"scene_index": i, "start_ms": a, "end_ms": b, "duration_ms": b - a}
                               for i, (a, b) in enumerate(zip(ts, ts[1:] + [end]))]
                     return {"scenes": scenes}
+                from .frames import EndOfStream
+
                 sad = []
                 prev = None
-                for lo in range(0, n, chunk):
-                    y = np.ascontiguousarray(src.luma_planes(lo, min(chunk, n - lo)))
+                y = None
+                lo = 0
+                while lo < n:
+                    want = min(chunk, n - lo)
+                    try:
+                        y = np.ascontiguousarray(src.luma_planes(lo, want))
+                    except EndOfStream:
+                        break  # the header's frame count was an estimate: the stream ended early
                     sad.append(scene.luma_sad(y, prev))
                     prev = y[-1]
+                    lo += len(y)
+                    if len(y) < want:
+                        break
                 sad = np.concatenate(sad) if sad else np.zeros(0, np.uint64)
-                count = int(y.shape[1] * y.shape[2]) if n else 1
+                count = int(y.shape[1] * y.shape[2]) if y is not None else 1
                 _, score = scene.ffmpeg_scene_scores(sad, count)
                 cut_ms = [int(float(scene.pts_time_string(int(c), tb_num, tb_den)) * 1000)
                           for c in np.nonzero(score > float(threshold))[0]]

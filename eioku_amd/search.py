@@ -83,6 +83,66 @@ class IndexFlatL2:
                    "eioku_index_search")
         return D, I
 
+    def search_after(self, q, k: int, after_D, after_I):
+        """The next ``k`` results after a previous answer: rows with ``(distance, id) > (after_D[q], after_I[q])``
+        in the result order (``after_*``: shape ``(nq,)``, same side of PCIe as ``q``)."""
+        nq, d = (int(s) for s in q.shape)
+        if d != self.d:
+            raise ValueError(f"expected dimension {self.d}, got {d}")
+        if on_device(q):
+            import torch
+
+            D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            after_D = after_D.to(torch.float32).contiguous()
+            after_I = after_I.to(torch.int64).contiguous()
+            mem = _lib.MEM_DEVICE
+        else:
+            q = np.ascontiguousarray(q, dtype=np.float32)
+            after_D = np.ascontiguousarray(after_D, dtype=np.float32)
+            after_I = np.ascontiguousarray(after_I, dtype=np.int64)
+            D = np.empty((nq, k), dtype=np.float32)
+            I = np.empty((nq, k), dtype=np.int64)
+            mem = _lib.MEM_HOST
+        _lib.check(self._lib.eioku_index_search_after(self._h, ptr(q), nq, int(k), ptr(after_D), ptr(after_I), ptr(D),
+                                                      ptr(I), mem, current_stream(q)), "eioku_index_search_after")
+        return D, I
+
+    def search_many(self, q, k: int):
+        """``search`` for any ``k``: rounds of at most 32 results chained with :meth:`search_after`."""
+        if k <= 32:
+            return self.search(q, k)
+        parts_d, parts_i = [], []
+        got = 0
+        while got < k:
+            kk = min(32, k - got)
+            if not parts_d:
+                D, I = self.search_after(q, kk, *self._before_everything(q))
+            else:
+                D, I = self.search_after(q, kk, parts_d[-1][:, -1], parts_i[-1][:, -1])
+            parts_d.append(D)
+            parts_i.append(I)
+            got += kk
+        if on_device(q):
+            import torch
+
+            return torch.cat(parts_d, 1), torch.cat(parts_i, 1)
+        return np.concatenate(parts_d, 1), np.concatenate(parts_i, 1)
+
+    @staticmethod
+    def _before_everything(q):
+        nq = int(q.shape[0])
+        if on_device(q):
+            import torch
+
+            return (torch.full((nq,), -1.0, dtype=torch.float32, device=q.device),
+                    torch.full((nq,), -1, dtype=torch.int64, device=q.device))
+        return np.full((nq,), -1.0, np.float32), np.full((nq,), -1, np.int64)
+
+    def set_param(self, name: str, value: int) -> None:
+        """Knobs of the wide-search path (``eioku_index_set_param``): scan_mode, scan_cap, scan_min_rows, ..."""
+        _lib.check(self._lib.eioku_index_set_param(self._h, name.encode(), int(value)), f"eioku_index_set_param({name})")
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.eioku_index_destroy(self._h)

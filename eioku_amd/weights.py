@@ -159,12 +159,37 @@ class _Stub:
         self.__dict__.update(state if isinstance(state, dict) else {"_state": state})
 
 
+# globals a checkpoint may legitimately reference: tensor reconstruction, plain containers and numpy scalars/arrays.
+# Everything else (``ultralytics.*`` model classes, ``torch.nn`` modules, anything importable) becomes an inert
+# ``_Stub`` that only stores its state - a checkpoint from MODEL_CACHE_DIR cannot run code through ``__reduce__``.
+_ALLOWED_GLOBALS = {
+    ("collections", "OrderedDict"), ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "dict"),
+    ("builtins", "list"), ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"),
+    ("builtins", "str"), ("builtins", "bytes"), ("builtins", "complex"), ("builtins", "slice"), ("builtins", "range"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
+    ("torch.serialization", "_get_layout"), ("torch._tensor", "_rebuild_from_type_v2"), ("torch", "Tensor"),
+    ("torch.nn.parameter", "Parameter"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "ndarray"), ("numpy", "dtype"),
+}
+_ALLOWED_PREFIXES = (("torch", "Storage"),)  # torch.FloatStorage, HalfStorage, ... (typed storage tags)
+
+
 class _TolerantUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        try:
-            return super().find_class(module, name)
-        except (ImportError, AttributeError):
-            return type(name, (_Stub,), {"__module__": module})
+        ok = (module, name) in _ALLOWED_GLOBALS or any(module == m and name.endswith(sfx) for m, sfx in _ALLOWED_PREFIXES)
+        if not ok and module == "torch":  # dtypes (torch.float16 ...) and legacy tensor types pickle as torch globals
+            import torch
+
+            obj = getattr(torch, name, None)
+            ok = isinstance(obj, torch.dtype) or (isinstance(obj, type) and issubclass(obj, torch.Tensor))
+        if ok:
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                pass
+        return type(name, (_Stub,), {"__module__": module})
 
 
 class _TolerantPickle:
@@ -190,7 +215,40 @@ def _walk_modules(obj, prefix, out, seen):
         _walk_modules(m, f"{prefix}{k}.", out, seen)
 
 
-def load_state(path: str | Path, variant: str, nc: int) -> dict[str, tuple[np.ndarray, np.ndarray]]:
+def _names_of(obj) -> dict[int, str] | None:
+    """``model.names`` of an Ultralytics checkpoint (what the reference reads as ``result.names``,
+    ``model_manager.py:281``): a dict or list on the model object."""
+    seen = set()
+    stack = [obj]
+    while stack:
+        o = stack.pop()
+        if id(o) in seen or o is None:
+            continue
+        seen.add(id(o))
+        d = o if isinstance(o, dict) else getattr(o, "__dict__", None)
+        if not isinstance(d, dict):
+            continue
+        names = d.get("names")
+        if isinstance(names, (list, tuple)) and names and all(isinstance(v, str) for v in names):
+            return dict(enumerate(names))
+        if isinstance(names, dict) and names and all(isinstance(v, str) for v in names.values()):
+            return {int(k): v for k, v in names.items()}
+        for key in ("ema", "model"):
+            if isinstance(d.get(key), (dict, _Stub)):
+                stack.append(d[key])
+    return None
+
+
+def load_checkpoint(path: str | Path, variant: str, nc: int):
+    """``(state, names)``: :func:`load_state` plus the checkpoint's own class names (``None`` when it has none,
+    e.g. a bare state_dict / .npz / .safetensors): a custom-trained ``yolov8*.pt`` labels its detections with
+    ITS names, as the reference's ``result.names[class_id]`` does."""
+    holder: dict = {}
+    state = load_state(path, variant, nc, _names_out=holder)
+    return state, holder.get("names")
+
+
+def load_state(path: str | Path, variant: str, nc: int, _names_out: dict | None = None) -> dict[str, tuple[np.ndarray, np.ndarray]]:
     """Read ``.pt`` (Ultralytics checkpoint or plain state_dict), ``.safetensors`` or ``.npz``."""
     path = Path(path)
     if not path.exists():
@@ -213,6 +271,10 @@ def load_state(path: str | Path, variant: str, nc: int) -> dict[str, tuple[np.nd
             if isinstance(ckpt, dict):
                 root = ckpt.get("ema") or ckpt.get("model")
             _walk_modules(root, "", tensors, set())
+            if _names_out is not None:
+                names = _names_of(ckpt)
+                if names is not None:
+                    _names_out["names"] = names
         if not tensors:
             raise ValueError(f"no tensors found in {path}")
     tensors = {re.sub(r"^(module\.|model\.model\.)", lambda m: "" if m.group(1) == "module." else "model.", k): v
