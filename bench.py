@@ -13,11 +13,14 @@ videos shard one-per-GPU, no data-path collective.  Rank 0 prints
 `roofline` is the dominant kernel's algorithmic work / its HIP-event duration measured on the launch
 stream inside the timed region; `cpu_baseline` is the CPU oracle on a bounded sample (rank 0, N=1).
 The kNN part runs after the timed frames region: rows sharded over ranks, replicated queries, one
-RCCL all-gather + local merge per search.  See DESIGN.md "Measurement".
+RCCL all-gather + local merge per search.  `frames_1080p` repeats the frames measurement on the north star's
+own source size (64 x 1080 x 1920 BGR frames per step: bilinear letterbox to 384 x 640) with its own roofline.
+See DESIGN.md "Measurement".
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -55,7 +58,19 @@ def parse_args():
     ap.add_argument("--prof-every", type=int, default=-1,
                     help="HIP-event kernel timing on every n-th timed step (0: off, -1: one step in the middle of the region)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU oracle sample budget")
+    ap.add_argument("--no-1080p", action="store_true", help="skip the frames_1080p block")
+    ap.add_argument("--knn-mode", type=int, default=-1, help="scan_mode of the index (-1: library default)")
     return ap.parse_args()
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: ties a committed PMC traffic measurement to the code it was taken on
+    (the GPU box has no .git, so a commit id cannot be read there)."""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "eioku_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 class Pipeline:
@@ -63,14 +78,14 @@ class Pipeline:
 
     BUILT = ("scene", "detect", "embed")
 
-    def __init__(self, args, device, rank):
+    def __init__(self, args, device, rank, height=None, width=None):
         import torch
 
         from eioku_amd import detect, embed, synth
 
         self.args = args
         self.device = device
-        self.batch, self.h, self.w = args.batch, args.height, args.width
+        self.batch, self.h, self.w = args.batch, height or args.height, width or args.width
         want = [s for s in args.stages.split(",") if s]
         self.stages = [s for s in want if s in self.BUILT]
         self.missing = [s for s in ("scene", "detect", "embed") if s not in self.stages]
@@ -135,6 +150,29 @@ class Pipeline:
                 self.prev = f[-1]
         self.last = out
 
+    def close(self):
+        if self.pdet is not None:
+            self.pdet.close()
+        elif self.det is not None:
+            self.det.close()
+        if self.enc is not None:
+            self.enc.close()
+
+    def scene_kernels(self):
+        """K1 / K2 of the profiled step: algorithmic bytes (W*H and 3*W*H per frame) over their
+        HIP-event durations."""
+        from eioku_amd import _lib
+
+        out = {}
+        for name, tag, bpf in (("k_sad_luma", _lib.PROF_SCENE_SAD, 1.0), ("k_hsv_sums", _lib.PROF_SCENE_HSV, 3.0)):
+            ms, cnt = _lib.prof_read(tag)
+            if cnt and ms > 0:
+                alg = bpf * self.h * self.w * self.batch * cnt
+                out[name] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": alg / (ms * 1e-3) / 1e9,
+                             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_kernel_ms": ms / cnt, "launches": cnt,
+                             "algorithmic_bytes_per_launch": alg / cnt}
+        return out
+
     def dominant(self):
         from eioku_amd import _lib
 
@@ -162,13 +200,16 @@ def knn_part(args, device, rank, world):
     xb = synth.normal_f32(21 + rank, hi - lo, d, device, l2_normalise=True)
     q = synth.normal_f32(22, args.knn_nq, d, device, l2_normalise=True)  # same queries on every rank
     ix = search.IndexFlatL2(d)
+    if args.knn_mode >= 0:
+        ix.set_param("scan_mode", args.knn_mode)
+    mode = args.knn_mode if args.knn_mode >= 0 else 2
     ix.attach(xb)
     sh = search.ShardedFlatL2(ix, lo)
-    sh.search(q, k)  # warm-up (allocates workspaces)
+    sh.search(q, k)  # warm-up (allocates workspaces; the wide path builds its bf16 planes of the rows here: index build)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    _lib.prof_enable(True)
+    _lib.prof_enable(True, tags=[_lib.PROF_KNN])
     _lib.prof_reset()
     t0 = time.perf_counter()
     for _ in range(args.knn_iters):
@@ -184,29 +225,40 @@ def knn_part(args, device, rank, world):
         dt = float(t.item())
     ms, cnt = _lib.prof_read(_lib.PROF_KNN)
     per = dt / args.knn_iters
-    passes = (args.knn_nq + 31) // 32
-    alg_bytes = float(hi - lo) * d * 4 * passes  # N*d*4 bytes per 32-query pass, this rank's shard
+    rows = float(hi - lo)
     kernel_s = max(ms * 1e-3 / max(cnt, 1), 1e-9)
-    flops = 2.0 * args.knn_nq * (hi - lo) * d
+    flops = 2.0 * args.knn_nq * rows * d          # 2 * nq * N * d
+    one_pass = rows * d * 4                       # the fp32 rows, once
+    scan = args.knn_nq > 64 and rows >= 262144 and mode != 0
     out = {"metric": f"kNN QPS@top-10 over {args.knn_n}x{d}", "value": args.knn_nq / per, "unit": "queries/s",
            "nq": args.knn_nq, "k": k, "ms_per_search": per * 1e3, "n_total": args.knn_n, "rows_per_gpu": hi - lo,
-           "dtype": "f32 (split-bf16 products, fp32 accumulate)" if args.knn_nq > 64 else "f32", "collective": "none" if world == 1 else "all_gather_into_tensor (RCCL) of nq*k*16 B per rank",
-           "roofline": None}
-    streamed = float(hi - lo) * d * 4 * ((args.knn_nq + 127) // 128 if args.knn_nq > 64 else passes)
-    if args.knn_nq > 64:
-        # wide split-bf16 kernel: 3 bf16 MFMAs per 16 dims (7.5 ms of matrix pipe per 1024 x 10M search) and one pass
-        # over the fp32 database per 128 queries (123 GB, 15.4 ms at 8 TB/s): HBM is the roofline that binds
-        out["roofline"] = {"kernel": "k_flat_l2_bf (split-bf16 MFMA, one DB pass per 128 queries)", "bound": "hbm",
-                           "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": streamed / kernel_s / 1e9,
-                           "frac": streamed / kernel_s / 1e9 / HBM_PEAK_GBS,
-                           "mfma_bf16_TFLOPs_executed": 3 * flops / kernel_s / 1e12}
+           "collective": "none" if world == 1 else "all_gather_into_tensor (RCCL) of nq*k*16 B per rank"}
+    if scan:
+        terms = 3 if mode == 1 else 1
+        streamed = rows * d * 2 * (2 if terms == 3 else 1)  # bf16 hi (+ lo) plane, each read exactly once
+        out["dtype"] = ("f32 results: bf16 hi-plane filter with a rigorous margin on the matrix cores, exact fp32 re-rank of "
+                        "the candidates" if terms == 1 else "f32 results from split-bf16 products (3 MFMA terms), fp32 accumulate")
+        out["roofline"] = {"kernel": f"k_l2_scan (row tiles stationary in registers, {terms}-term bf16 MFMA, every query tile "
+                                     "streamed past them from L2; one HBM pass per search)",
+                           "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F16_PEAK_TFLOPS,
+                           "achieved": flops / kernel_s / 1e12, "frac": flops / kernel_s / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                           "mfma_bf16_TFLOPs_executed": terms * flops / kernel_s / 1e12,
+                           "algorithmic_bytes_one_pass": one_pass, "algorithmic_GBps": one_pass / kernel_s / 1e9,
+                           "hbm_bytes_streamed_per_launch": streamed, "hbm_GBps_streamed": streamed / kernel_s / 1e9,
+                           "note": "achieved = SURVEY 8d's 2*nq*N*d over the scan kernel's HIP-event duration; the sample "
+                                   "search, candidate selection and merge launches are inside ms_per_search, not in it"}
     else:
-        out["roofline"] = {"kernel": "k_flat_l2 (narrow: one DB pass per 32 queries)", "bound": "hbm", "unit": "GB/s",
-                           "peak": HBM_PEAK_GBS, "achieved": alg_bytes / kernel_s / 1e9,
-                           "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS}
-    out["roofline"].update({"avg_kernel_ms": kernel_s * 1e3, "algorithmic_flops_per_launch": flops,
-                            "algorithmic_bytes_per_32query_pass": float(hi - lo) * d * 4,
-                            "hbm_bytes_streamed_per_launch": streamed})
+        passes = (args.knn_nq + 31) // 32
+        wide = args.knn_nq > 64
+        streamed = one_pass * ((args.knn_nq + 127) // 128 if wide else passes)
+        out["dtype"] = "f32 (split-bf16 products, fp32 accumulate)" if wide else "f32"
+        out["roofline"] = {"kernel": "k_flat_l2_bf (query tiles in registers: one DB pass per 128 queries)" if wide
+                           else "k_flat_l2 (narrow: one DB pass per 32 queries)", "bound": "hbm", "unit": "GB/s",
+                           "peak": HBM_PEAK_GBS, "achieved": one_pass * (1 if wide else passes) / kernel_s / 1e9,
+                           "frac": one_pass * (1 if wide else passes) / kernel_s / 1e9 / HBM_PEAK_GBS,
+                           "algorithmic_TFLOPs": flops / kernel_s / 1e12,
+                           "hbm_bytes_streamed_per_launch": streamed, "hbm_GBps_streamed": streamed / kernel_s / 1e9}
+    out["roofline"].update({"avg_kernel_ms": kernel_s * 1e3, "algorithmic_flops_per_launch": flops})
     ix.close()
     del xb
     torch.cuda.empty_cache()
@@ -276,17 +328,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
-    pipe = Pipeline(args, device, rank)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        pipe.step(i)
-    barrier()
-    # HIP-event hooks bracket every conv launch on the kernel's own stream; they are sampled (every
+    # HIP-event hooks bracket every tagged launch on the kernel's own stream; they are sampled (every
     # --prof-every-th step of the timed region, run un-overlapped) because 2 event records per launch x ~130
     # launches per step are themselves ~15% of a step and because overlapped stages stretch each other's kernels
     def profiled(i):
@@ -294,67 +341,94 @@ def main():
             return i == args.steps // 2
         return args.prof_every > 0 and i % args.prof_every == 0
 
-    _lib.prof_reset()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if profiled(i):
-            torch.cuda.synchronize()  # drain the overlapped steps, time this one's kernels alone, drain again
-            _lib.prof_enable(True, tags=[_lib.PROF_CONV if pipe.det is not None else _lib.PROF_SCENE_HSV])
-            pipe.step(i, serial=True)
-            torch.cuda.synchronize()
-            _lib.prof_enable(False)
-        else:
+    def run_frames(height, width):
+        """warm-up, then EXACTLY args.steps timed steps between barrier + synchronize pairs; max over ranks."""
+        pipe = Pipeline(args, device, rank, height, width)
+        for i in range(args.warmup):
             pipe.step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    _lib.prof_enable(False)
-    pipe.prof_steps = sum(1 for i in range(args.steps) if profiled(i))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        barrier()
+        _lib.prof_reset()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if profiled(i):
+                torch.cuda.synchronize()  # drain the overlapped steps, time this one's kernels alone, drain again
+                _lib.prof_enable(True, tags=[_lib.PROF_CONV, _lib.PROF_SCENE_HSV, _lib.PROF_SCENE_SAD])
+                pipe.step(i, serial=True)
+                torch.cuda.synchronize()
+                _lib.prof_enable(False)
+            else:
+                pipe.step(i)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        _lib.prof_enable(False)
+        pipe.prof_steps = sum(1 for i in range(args.steps) if profiled(i))
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        dom = pipe.dominant()
+        # HBM traffic of the dominant kernel family from PMC counters (tools/pmc_traffic.sh: separate FETCH_SIZE /
+        # WRITE_SIZE passes, gfx950 x2 read correction), measured on this exact workload and committed together with the
+        # hash of the kernel sources it was taken on; a measurement of other code is refused, not reported
+        traffic, tnote = None, None
+        tfile = ROOT / "profiles" / f"traffic_conv_{Path(args.model).stem}_{args.batch}x{height}x{width}.json"
+        if pipe.det is not None and tfile.exists():
+            t = json.loads(tfile.read_text())
+            if t.get("csrc_sha16") == kernel_source_hash():
+                traffic = t["hbm_bytes_per_forward"]
+                tnote = "HBM bytes per step (all conv launches), PMC FETCH_SIZE x2 + WRITE_SIZE, taken on these kernel sources"
+            else:
+                tnote = f"{tfile.name} was measured on other kernel sources ({t.get('csrc_sha16')}): refused"
+        avg_ms = dom["ms_total"] / max(dom["launches"], 1)
+        achieved = dom["alg_total"] / (dom["ms_total"] * 1e-3) / dom["scale"] if dom["ms_total"] > 0 else 0.0
+        note = "" if not pipe.missing else f"; stages NOT run (value is not the full metric): {', '.join(pipe.missing)}"
+        res = {
+            "value": args.batch * args.steps * world / elapsed,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "dtype": "f16" if pipe.det is not None else "u8",
+            "config": {"workload": f"{args.batch}x{height}x{width} BGR u8 frames/step/GPU resident in HBM: "
+                                   f"scene (HSV ContentDetector sums + luma SAD) on every frame, {args.model} (random-init, "
+                                   f"fp16) detect on every frame, all-MiniLM-L6-v2 (random-init, fp32) on {args.segments} "
+                                   f"segments x {args.seq_len} tokens per step; stages run: {', '.join(pipe.stages)}{note}",
+                       "batch": args.batch, "frame": [height, width], "parallelism": f"shard-by-video x{world}"},
+            "roofline": {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": achieved, "peak": dom["peak"],
+                         "unit": dom["unit"], "frac": achieved / dom["peak"], "traffic": traffic, "traffic_note": tnote,
+                         "avg_kernel_ms": avg_ms, "launches": dom["launches"],
+                         "kernel_ms_per_step": dom["ms_total"] / max(pipe.prof_steps, 1), "profiled_steps": pipe.prof_steps,
+                         "algorithmic_per_step": dom["alg_per_step"], "scene_kernels": pipe.scene_kernels()},
+        }
+        stages = list(pipe.stages)
+        pipe.close()
+        del pipe
+        torch.cuda.empty_cache()
+        return res, stages
 
-    dom = pipe.dominant()
-    # HBM traffic of the dominant kernel family from PMC counters (tools/pmc_traffic.sh: separate FETCH_SIZE /
-    # WRITE_SIZE passes, gfx950 x2 read correction), measured offline on this exact workload and committed
-    traffic = None
-    tfile = ROOT / "profiles" / f"r01_traffic_conv_{Path(args.model).stem}_{args.batch}x{args.height}x{args.width}.json"
-    if pipe.det is not None and tfile.exists():
-        traffic = json.loads(tfile.read_text())["hbm_bytes_per_forward"]
-    avg_ms = dom["ms_total"] / max(dom["launches"], 1)
-    achieved = dom["alg_total"] / (dom["ms_total"] * 1e-3) / dom["scale"] if dom["ms_total"] > 0 else 0.0
-    frames_total = args.batch * args.steps * world
-    note = "" if not pipe.missing else f"; stages NOT run (value is not the full metric): {', '.join(pipe.missing)}"
+    head, stages = run_frames(args.height, args.width)
     out = {
         "metric": "frames/sec (scene+detect+embed) per node",
-        "value": frames_total / elapsed,
+        "value": head["value"],
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f16" if pipe.det is not None else "u8",
+        "dtype": head["dtype"],
         "data": "synthetic",
-        "config": {"workload": f"{args.batch}x{args.height}x{args.width} BGR u8 frames/step/GPU resident in HBM: "
-                               f"scene (HSV ContentDetector sums + luma SAD) on every frame, {args.model} (random-init, "
-                               f"fp16) detect on every frame, all-MiniLM-L6-v2 (random-init, fp32) on {args.segments} "
-                               f"segments x {args.seq_len} tokens per step; stages run: {', '.join(pipe.stages)}{note}",
-                   "batch": args.batch, "frame": [args.height, args.width], "parallelism": f"shard-by-video x{world}"},
-        "roofline": {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": achieved, "peak": dom["peak"],
-                     "unit": dom["unit"], "frac": achieved / dom["peak"], "traffic": traffic,
-                     "traffic_note": "HBM bytes per step (all conv launches), PMC FETCH_SIZE x2 + WRITE_SIZE" if traffic else None,
-                     "avg_kernel_ms": avg_ms, "launches": dom["launches"], "kernel_ms_per_step": dom["ms_total"] / max(pipe.prof_steps, 1), "profiled_steps": pipe.prof_steps,
-                     "algorithmic_per_step": dom["alg_per_step"]},
+        "config": head["config"],
+        "roofline": head["roofline"],
     }
+    if not args.no_1080p and (args.height, args.width) != (1080, 1920):
+        # the north star's own source size: 1080p frames, bilinear letterbox to 384 x 640 (the reference's
+        # model_manager.py:263-275 on a 1920 x 1080 file); same three stages, same steps / warm-up
+        blk, _ = run_frames(1080, 1920)
+        out["frames_1080p"] = {"metric": out["metric"], "unit": "frames/s", "steps": args.steps, "warmup": args.warmup, **blk}
     if args.knn_n > 0:
-        del pipe
-        torch.cuda.empty_cache()
         out["knn"] = knn_part(args, device, rank, world)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, [s for s in args.stages.split(",") if s in Pipeline.BUILT])
+        out["cpu_baseline"] = cpu_baseline(args, stages)
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

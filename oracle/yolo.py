@@ -85,13 +85,13 @@ def letterbox(img: np.ndarray, imgsz: int = 640, stride: int = 32, auto: bool = 
     return out, (top, left)
 
 
-def preprocess(frames_bgr: np.ndarray, imgsz: int = 640):
-    """BGR u8 (n,h,w,3) -> fp16-valued float32 NCHW RGB /255 (``im.half(); im /= 255``)."""
+def preprocess(frames_bgr: np.ndarray, imgsz: int = 640, fp16: bool = True):
+    """BGR u8 (n,h,w,3) -> float32 NCHW RGB /255, fp16-valued unless ``fp16=False`` (``im.float(); im /= 255``)."""
     import torch
 
     lb = np.stack([letterbox(f, imgsz)[0] for f in frames_bgr])
     x = torch.from_numpy(lb[..., ::-1].copy()).permute(0, 3, 1, 2).float()
-    return (x / 255.0).half().float()
+    return (x / 255.0).half().float() if fp16 else x / 255.0
 
 
 # --------------------------------------------------------------------------------------------
@@ -103,13 +103,22 @@ def _h(t):
 
 
 class Net:
-    def __init__(self, state: dict, variant_ch, variant_depth, nc: int):
+    """``fp16=True`` (default): the fp16 network the HIP path runs.  ``fp16=False``: the reference's own arithmetic
+    (Ultralytics predicts with ``half=False``, ``model_manager.py:270-275``): fp32 weights and activations - the
+    validation mode SURVEY.md 7 asks for, used to bound the fp16 build's drift from the reference."""
+
+    def __init__(self, state: dict, variant_ch, variant_depth, nc: int, fp16: bool = True):
         import torch
 
         self.nc = nc
+        self.fp16 = fp16
         self.ch, self.depth = variant_ch, variant_depth
-        self.p = {k: (torch.from_numpy(np.asarray(w, np.float32)).half().float(), torch.from_numpy(np.asarray(b, np.float32)))
+        rw = (lambda t: t.half().float()) if fp16 else (lambda t: t)
+        self.p = {k: (rw(torch.from_numpy(np.asarray(w, np.float32))), torch.from_numpy(np.asarray(b, np.float32)))
                   for k, (w, b) in state.items()}
+
+    def _h(self, t):
+        return t.half().float() if self.fp16 else t
 
     def conv(self, name, x, stride=1, act=True, keep_f32=False):
         import torch
@@ -119,7 +128,7 @@ class Net:
         y = F.conv2d(x, w, b, stride=stride, padding=w.shape[-1] // 2)
         if act:
             y = y * torch.sigmoid(y)
-        return y if keep_f32 else _h(y)
+        return y if keep_f32 else self._h(y)
 
     def c2f(self, p, x, n, shortcut):
         import torch
@@ -127,7 +136,7 @@ class Net:
         y = list(self.conv(f"{p}.cv1.conv", x).chunk(2, 1))
         for i in range(n):
             t = self.conv(f"{p}.m.{i}.cv2.conv", self.conv(f"{p}.m.{i}.cv1.conv", y[-1]))
-            y.append(_h(y[-1] + t) if shortcut else t)
+            y.append(self._h(y[-1] + t) if shortcut else t)
         return self.conv(f"{p}.cv2.conv", torch.cat(y, 1))
 
     def sppf(self, x):
@@ -139,8 +148,10 @@ class Net:
             y.append(F.max_pool2d(y[-1], 5, 1, 2))
         return self.conv("model.9.cv2.conv", torch.cat(y, 1))
 
-    def forward(self, x):
-        """x: float32 NCHW (fp16-valued).  Returns (box[3], cls[3]) float32 NHWC numpy arrays."""
+    def forward(self, x, penultimate: bool = False):
+        """x: float32 NCHW (fp16-valued).  Returns (box[3], cls[3]) float32 NHWC numpy arrays; with ``penultimate``
+        also the inputs of the six Detect output convs (``[box feat[3], cls feat[3]]``, NHWC) - tests build
+        well-conditioned heads on top of them."""
         import torch
         import torch.nn.functional as F
 
@@ -160,12 +171,17 @@ class Net:
             x15 = self.c2f("model.15", torch.cat([F.interpolate(x12, scale_factor=2, mode="nearest"), x4], 1), d0, False)
             x18 = self.c2f("model.18", torch.cat([self.conv("model.16.conv", x15, 2), x12], 1), d0, False)
             x21 = self.c2f("model.21", torch.cat([self.conv("model.19.conv", x18, 2), x9], 1), d0, False)
-            box, cls = [], []
+            box, cls, fb, fc = [], [], [], []
             for l, f in enumerate((x15, x18, x21)):
                 b = self.conv(f"model.22.cv2.{l}.1.conv", self.conv(f"model.22.cv2.{l}.0.conv", f))
                 c = self.conv(f"model.22.cv3.{l}.1.conv", self.conv(f"model.22.cv3.{l}.0.conv", f))
                 box.append(self.conv(f"model.22.cv2.{l}.2", b, act=False, keep_f32=True).permute(0, 2, 3, 1).contiguous().numpy())
                 cls.append(self.conv(f"model.22.cv3.{l}.2", c, act=False, keep_f32=True).permute(0, 2, 3, 1).contiguous().numpy())
+                if penultimate:
+                    fb.append(b.permute(0, 2, 3, 1).contiguous().numpy())
+                    fc.append(c.permute(0, 2, 3, 1).contiguous().numpy())
+        if penultimate:
+            return box, cls, fb, fc
         return box, cls
 
 

@@ -146,3 +146,27 @@ def test_384d_m48_shapes_and_sharded_merge(gpu):
     _, It = oknn.search(x, q, 10)
     rec = np.mean([len(set(Iw.cpu().numpy()[i]) & set(It[i])) / 10 for i in range(len(q))])
     assert rec > 0.1, rec  # chance level is 10/12000
+
+
+def test_nprobe_above_32_matches_the_oracle_scan(gpu):
+    """nprobe > 32 used to fail (probe selection is an IndexFlatL2 search, k <= 32 per call); rounds of 32
+    chained with eioku_index_search_after now serve any nprobe.  nlist 96 / nprobe 64: same codebooks as the oracle ->
+    same probed lists, ADC distances to 1e-5, and probing every list equals probing 64 when the rest hold no winner."""
+    d, nlist, m = 64, 96, 8
+    x = clustered(3, 9000, d, ncl=96)
+    o = oivf.IVFPQ(d, nlist, m)
+    o.train(x[:6000])
+    o.add(x)
+    ix = ivfpq.IndexIVFPQ(d, nlist, m)
+    ix.set_codebooks(o.coarse, o.pq)
+    ix.add(x)
+    q = clustered(4, 50, d, ncl=96)
+    for nprobe in (33, 64, 96):
+        ix.nprobe = o.nprobe = nprobe
+        D, I = (t.cpu().numpy() for t in ix.search(q, 10))
+        Do, Io = o.search(q, 10)
+        assert (I == Io).mean() > 0.97, nprobe
+        assert np.allclose(D, Do, rtol=1e-4, atol=1e-5) or (np.abs(D - Do) < 1e-4).mean() > 0.97
+    Dt, It = oknn.search(x, q, 10)
+    recall = np.mean([len(set(I[i]) & set(It[i])) / 10 for i in range(len(q))])
+    assert recall > 0.5  # every list probed: only the PQ quantisation separates it from the exact answer

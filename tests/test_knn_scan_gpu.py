@@ -1,0 +1,181 @@
+"""GPU parity of the wide-search ("scan") path of K9: database tiles stationary in registers, every query tile
+streamed past them, per-query candidate lists bounded by an exact search of a strided sample, k-best selection
+(csrc/knn.hip: k_split_planes / k_l2_scan / k_scan_select).
+
+Same bar as test_knn_gpu.py: distances within 1e-4 relative of the float64 truth, ids identical wherever the truth
+is separated by more than that.  scan_mode 1 = three-term split-bf16 products (candidate distances are final),
+2 = one-term bf16 filter with a rigorous margin + exact fp32 re-rank.  `scan_min_rows` is lowered so that small
+databases take the path; the full-size case runs at BASELINE's 10 M x 384."""
+import numpy as np
+import pytest
+
+from oracle import knn as oknn
+from eioku_amd import search, synth
+from test_knn_gpu import check, unit_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def scan_index(d, mode, **params):
+    ix = search.IndexFlatL2(d)
+    ix.set_param("scan_min_rows", 4096)
+    ix.set_param("scan_mode", mode)
+    for k, v in params.items():
+        ix.set_param(k, v)
+    return ix
+
+
+@pytest.mark.parametrize("n,nq,k,d,mode,waves", [
+    (20000, 70, 10, 384, 1, 0), (20000, 70, 10, 384, 2, 0), (5000, 130, 10, 128, 2, 0), (33333, 200, 16, 256, 2, 4),
+    (33333, 200, 5, 256, 1, 0), (4099, 65, 2, 384, 2, 8), (50001, 97, 10, 384, 2, 4), (8192, 1024, 10, 384, 1, 0),
+])
+def test_scan_matches_float64_truth(gpu, n, nq, k, d, mode, waves):
+    xb = unit_rows(31, n, d)
+    xq = unit_rows(32, nq, d)
+    xq[:4] = xb[[5, n // 2, n - 1, 5]] + 0.002 * xq[:4]  # near neighbours (tiny distances: the cancellation regime)
+    ix = scan_index(d, mode, scan_waves=waves)
+    ix.add(xb)
+    D, I = ix.search(xq, k)
+    Dt, It = oknn.search(xb, xq, k)
+    check(D, I, Dt, It, xb, xq)
+    ix.close()
+
+
+def test_scan_agrees_with_register_tile_kernels_and_is_deterministic(gpu):
+    import torch
+
+    n, nq, d = 60000, 300, 384
+    xb = torch.from_numpy(unit_rows(41, n, d)).to(gpu)
+    xq = torch.from_numpy(unit_rows(42, nq, d)).to(gpu)
+    res = {}
+    for mode in (0, 1, 2):
+        ix = scan_index(d, mode)
+        ix.attach(xb)
+        res[mode] = [tuple(t.clone() for t in ix.search(xq, 10)) for _ in range(2)]
+        assert torch.equal(res[mode][0][0], res[mode][1][0]) and torch.equal(res[mode][0][1], res[mode][1][1])
+        ix.close()
+    for mode in (1, 2):
+        D0, I0 = res[0][0]
+        D, I = res[mode][0]
+        assert (I == I0).float().mean() > 0.999
+        assert torch.allclose(D, D0, rtol=1e-4, atol=2e-6)
+
+
+def test_candidate_list_overflow_falls_back_to_the_exact_kernels(gpu):
+    """A list of 16 slots cannot hold the ~20 candidates the sample bound admits per query: the overflow flag gates
+    the register-tile search in, and the answer is still the exact one (rule 26: force the rare branch)."""
+    n, nq, d = 20000, 100, 384
+    xb, xq = unit_rows(51, n, d), unit_rows(52, nq, d)
+    Dt, It = oknn.search(xb, xq, 10)
+    for mode in (1, 2):
+        ix = scan_index(d, mode, scan_cap=16)
+        ix.add(xb)
+        D, I = ix.search(xq, 10)
+        check(D, I, Dt, It, xb, xq)
+        ix.set_param("scan_cap", 8192)  # and back on the fast path with the same handle
+        D, I = ix.search(xq, 10)
+        check(D, I, Dt, It, xb, xq)
+        ix.close()
+
+
+def test_incremental_add_extends_the_planes_and_ties_order_by_id(gpu):
+    d = 384
+    xb = unit_rows(61, 17777, d)
+    xb[9000] = xb[123]
+    xb[17000] = xb[123]   # three copies of one row, one of them in the second add()
+    xq = unit_rows(62, 80, d)
+    xq[0] = xb[123]
+    ix = scan_index(d, 2)
+    ix.add(xb[:10000])
+    D, I = ix.search(xq, 10)
+    check(D, I, *oknn.search(xb[:10000], xq, 10), xb[:10000], xq)
+    assert list(I[0, :2]) == [123, 9000]
+    ix.add(xb[10000:])     # partial last tile of the first batch is rebuilt, the rest appended
+    D, I = ix.search(xq, 10)
+    check(D, I, *oknn.search(xb, xq, 10), xb, xq)
+    assert list(I[0, :3]) == [123, 9000, 17000] and np.all(D[0, :3] < 1e-5)
+    ix.set_param("scan_mode", 1)  # the lo plane did not exist yet: built on demand
+    D1, I1 = ix.search(xq, 10)
+    check(D1, I1, *oknn.search(xb, xq, 10), xb, xq)
+    assert list(I1[0, :3]) == [123, 9000, 17000]
+    ix.close()
+
+
+def test_more_than_1024_queries_run_in_groups(gpu):
+    n, nq, d = 30000, 1100, 128
+    xb, xq = unit_rows(71, n, d), unit_rows(72, nq, d)
+    ix = scan_index(d, 2)
+    ix.add(xb)
+    D, I = ix.search(xq, 10)
+    check(D, I, *oknn.search(xb, xq, 10), xb, xq)
+    ix.close()
+
+
+def test_unnormalised_vectors_keep_the_margin_rigorous(gpu):
+    """The one-term filter's margin scales with |q| |x|: rows of very different norms must not lose neighbours."""
+    rng = np.random.default_rng(5)
+    n, nq, d = 25000, 90, 384
+    xb = unit_rows(81, n, d) * rng.uniform(0.2, 6.0, (n, 1)).astype(np.float32)
+    xq = unit_rows(82, nq, d) * rng.uniform(0.2, 6.0, (nq, 1)).astype(np.float32)
+    ix = scan_index(d, 2)
+    ix.add(xb)
+    D, I = ix.search(xq, 10)
+    check(D, I, *oknn.search(xb, xq, 10), xb, xq)
+    ix.close()
+
+
+def test_search_after_and_search_many(gpu):
+    """eioku_index_search_after: the next k results after a previous answer; chained for k > 32 (IVF nprobe > 32)."""
+    n, nq, d = 3000, 7, 384
+    xb, xq = unit_rows(91, n, d), unit_rows(92, nq, d)
+    xb[2000] = xb[11]
+    xq[0] = xb[11]  # a tie at distance 0 across a round boundary must not be lost or repeated
+    ix = search.IndexFlatL2(d)
+    ix.add(xb)
+    Dt, It = oknn.search(xb, xq, 70)
+    D, I = ix.search_many(xq, 70)
+    assert D.shape == (nq, 70) and np.all(np.diff(D, axis=1) >= 0)
+    for q in range(nq):
+        assert len(set(I[q])) == 70
+    assert np.allclose(D, Dt, rtol=1e-4, atol=1e-6)
+    assert (I == It).mean() > 0.98 and list(I[0, :2]) == [11, 2000]
+    D1, I1 = ix.search(xq, 5)
+    D2, I2 = ix.search_after(xq, 5, D1[:, -1], I1[:, -1])
+    assert np.array_equal(np.concatenate([I1, I2], 1), I[:, :10])
+    small = search.IndexFlatL2(d)
+    small.add(xb[:40])
+    D, I = small.search_many(xq, 64)  # fewer rows than k: padded with -1
+    assert np.all(I[:, 40:] == -1) and np.all(I[:, :40] >= 0)
+    assert np.all(D[:, 40:] == np.finfo(np.float32).max)  # FAISS pads distances with FLT_MAX
+
+
+def test_full_size_10m_scan_equals_register_tile_search(gpu):
+    """BASELINE metric size (10 M x 384, generated in HBM): both scan modes return the register-tile kernels' ids,
+    planted copies come back first at distance ~0, and a strip of queries agrees with a torch fp64 brute force."""
+    import torch
+
+    n, d, nq, k = 10_000_000, 384, 1024, 10
+    xb = synth.normal_f32(21, n, d, gpu, l2_normalise=True)
+    q = synth.normal_f32(22, nq, d, gpu, l2_normalise=True)
+    plant = (torch.arange(0, 64, device=gpu) * 154_321 + 7) % n
+    q[:64] = xb[plant]
+    ix = search.IndexFlatL2(d)
+    ix.attach(xb)
+    ix.set_param("scan_mode", 0)
+    D0, I0 = ix.search(q, k)
+    for mode in (1, 2):
+        ix.set_param("scan_mode", mode)
+        D, I = ix.search(q, k)
+        assert torch.equal(I[:64, 0], plant) and float(D[:64, 0].max()) < 1e-5
+        assert (I == I0).float().mean() > 0.9995, mode
+        assert bool(((D - D0).abs() <= 5e-6 + 1e-4 * D0).all()), mode
+    # independent check of 16 queries against fp64 on device
+    q64 = q[60:76].double()
+    best = torch.full((16, k), float("inf"), dtype=torch.float64, device=gpu)
+    for lo in range(0, n, 500_000):
+        blk = xb[lo:lo + 500_000].double()
+        dd = (q64 * q64).sum(1)[:, None] + (blk * blk).sum(1)[None, :] - 2 * q64 @ blk.T
+        best = torch.cat([best, torch.topk(dd, k, dim=1, largest=False).values], 1).sort(dim=1).values[:, :k]
+    err = (D[60:76].double() - best.clamp(min=0)).abs()
+    assert bool((err <= 5e-6 + 1e-4 * best.abs()).all()), float(err.max())
+    ix.close()

@@ -7,7 +7,7 @@ geometry of the reference's frame sizes, the DFL expectation, torchvision's gree
 """
 import numpy as np
 
-from eioku_amd import detect as D
+from eioku_amd import detect as D, weights as W
 from oracle import yolo as oy
 
 
@@ -77,3 +77,29 @@ def test_scale_boxes_undoes_the_letterbox_and_clips():
     # 1080x1920 -> 384x640: gain 1/3, pad_y = round(12 - 0.1) = 12
     got = oy.scale_boxes(np.array([64.0, 12.0 + 30.0, 640.0 + 5, 384.0], np.float32), (384, 640), (1080, 1920))
     assert np.allclose(got, [192.0, 90.0, 1920.0, 1080.0], atol=1e-3)
+
+
+def test_margin_stable_detections_survive_every_perturbation_within_the_margin():
+    """tests/wellcond.py: an anchor declared margin-stable for drift (dc, du) stays kept, with its class, when every
+    class logit moves by a random amount that changes confidences by less than dc (soundness of the criterion the
+    GPU end-to-end test scopes its exact index comparison to)."""
+    import wellcond
+
+    frames = wellcond.blob_frames(5, 1, 135, 240)
+    state = wellcond.calibrated_state(frames, "n", 3, seed=7, frac=0.08)
+    net = oy.Net(state, *W.YOLO_VARIANTS["n"], 3)
+    ref, (box_maps, cls_maps, boxes, scores) = oy.detect(net, frames, 0.25)
+    kept = [d["anchor"] for d in ref[0]]
+    dc = 0.01
+    stable = wellcond.stably_kept(boxes[0], scores[0], kept, 0.25, dc, 1e-4)
+    assert 5 <= len(stable) <= len(kept) and set(stable) <= set(kept)
+    cls_of = {d["anchor"]: d["cls"] for d in ref[0]}
+    rng = np.random.default_rng(0)
+    for _ in range(6):
+        # |d sigmoid| <= |d logit| / 4: logits move by up to 3.9 dc, confidences by less than dc
+        pert = [c + rng.uniform(-3.9 * dc, 3.9 * dc, c.shape).astype(np.float32) for c in cls_maps]
+        b2, s2 = oy.decode(box_maps, pert)
+        assert np.abs(s2 - scores).max() < dc
+        out = oy.non_max_suppression(b2, s2, 0.25)[0]
+        got = {a: c for a, _, _, c in out}
+        assert all(a in got and got[a] == cls_of[a] for a in stable)

@@ -9,18 +9,23 @@ Bars (written here, as the tier asks):
                           mean <= HEAD_MEAN*rms
   K6+K7 decode + NMS      given IDENTICAL head maps: kept anchor indices, order and classes exact;
                           conf / box coordinates within BOX_RTOL (device expf vs numpy exp, ulps)
-  end to end              same kept set whenever the oracle's own result is stable under a
-                          perturbation of the size of the network tolerance
+  end to end              every MARGIN-STABLE detection (tests/wellcond.py: decided by more than the measured
+                          head drift) is kept by both sides with the same anchor index, class and order -
+                          exact, both directions, >= 20 of them per frame; objects (nc = 80) and faces (nc = 1)
+  fp32 validation         the HIP heads also stay within FP32_MAX / FP32_MEAN of the reference's own fp32
+                          arithmetic (Ultralytics half=False) run by the oracle's fp32 mode
 """
 import numpy as np
 import pytest
 
+import wellcond
 from eioku_amd import detect as D, weights as W
 from oracle import prng, yolo as oy
 
 pytestmark = pytest.mark.gpu
 
 HEAD_MAX, HEAD_MEAN = 0.025, 0.005
+FP32_MAX, FP32_MEAN = 0.05, 0.01  # vs the reference's fp32 arithmetic (tests/test_oracle_pins.py bounds the oracle's own)
 BOX_RTOL = 2e-5
 
 
@@ -71,7 +76,11 @@ def _check_heads(got, want, tag):
 
 
 @pytest.mark.parametrize("variant,nc,n,h,w", [("n", 80, 2, 96, 160), ("n", 1, 1, 64, 96), ("s", 80, 1, 64, 64),
-                                               ("m", 80, 1, 64, 96), ("n", 80, 1, 384, 640)])
+                                               ("m", 80, 1, 64, 96), ("n", 80, 1, 384, 640),
+                                               # BASELINE cfg4 / the live config at the network size every 16:9 source
+                                               # letterboxes to: YOLOv8m objects, yolov8n-face, yolov8s (content_creator.json)
+                                               ("m", 80, 1, 384, 640), ("n", 1, 1, 384, 640), ("s", 80, 1, 384, 640),
+                                               ("m", 80, 2, 640, 640)])
 def test_network_heads_match_fp16_oracle(gpu, variant, nc, n, h, w):
     import torch
 
@@ -86,6 +95,14 @@ def test_network_heads_match_fp16_oracle(gpu, variant, nc, n, h, w):
     _check_heads(box, rbox, (variant, "box"))
     _check_heads(cls, rcls, (variant, "cls"))
     assert det.last_conv_flops() > 0
+    if (h, w) == (384, 640) and variant in ("n", "m"):
+        # fp32 validation mode: the reference predicts with half=False; same weights, fp32 everywhere
+        f32 = oy.Net(state, *W.YOLO_VARIANTS[variant], nc, fp16=False)
+        fbox, fcls = f32.forward(torch.from_numpy(x[..., :3].astype(np.float32)).permute(0, 3, 1, 2))
+        for g, r in zip(box + cls, fbox + fcls):
+            err = np.abs(g.cpu().numpy() - r)
+            rms = float(np.sqrt((r.astype(np.float64) ** 2).mean()))
+            assert err.max() <= FP32_MAX * rms and err.mean() <= FP32_MEAN * rms, (variant, float(err.max() / rms))
     det.close()
 
 
@@ -117,13 +134,19 @@ def _stable(boxes, scores, conf, iou, max_det, ref):
 ])
 def test_decode_nms_indices_exact(gpu, seed, nc, cls_mu, cls_sigma, conf, max_det):
     n, hl, wl = 3, (48, 24, 12), (80, 40, 20)
-    box, cls = _random_heads(seed, n, hl, wl, nc, cls_mu, cls_sigma)
     plan = D.letterbox_plan(480, 854)
+    # well-conditioned by construction: a draw whose oracle answer would flip under an ulp-scale nudge of either
+    # threshold (a confidence within 1e-6 of `conf`, an IoU within 1e-5 of 0.7) says nothing about the kernels;
+    # walk a deterministic seed sequence to the first draw that has no such pair (almost always the first)
+    for attempt in range(8):
+        box, cls = _random_heads(seed + 1000 * attempt, n, hl, wl, nc, cls_mu, cls_sigma)
+        boxes, scores = oy.decode(box, cls)
+        ref = oy.non_max_suppression(boxes, scores, conf, 0.7, max_det)
+        if _stable(boxes, scores, conf, 0.7, max_det, ref):
+            break
+    else:
+        pytest.fail("no well-conditioned draw in 8 seeds: the conditioning check itself is broken")
     dets, counts = D.postprocess([_dev(b, gpu) for b in box], [_dev(c, gpu) for c in cls], plan, conf, 0.7, max_det)
-    boxes, scores = oy.decode(box, cls)
-    ref = oy.non_max_suppression(boxes, scores, conf, 0.7, max_det)
-    if not _stable(boxes, scores, conf, 0.7, max_det, ref):
-        pytest.skip("oracle result itself flips under ulp-scale threshold perturbation (ill-conditioned seed)")
     for i in range(n):
         k = int(counts[i])
         assert k == len(ref[i])
@@ -162,60 +185,103 @@ def test_nms_keeps_at_most_max_det_and_suppresses_duplicates(gpu):
 # ---------------------------------------------------------------------------------------------
 # end to end
 # ---------------------------------------------------------------------------------------------
-def _calibrated_state(frames, variant="n", nc=80, seed=7, frac=0.015):
-    """Random weights whose Detect logits are O(1) on THESE frames (a random net's logit scale depends
-    on its input): rescale the six output convs so box logits have std 2 and class logits std 3,
-    shifted so that about `frac` of the anchors pass conf 0.25 and none saturates."""
-    state = W.random_state(variant, nc, seed=seed)
-    box, cls = oy.Net(state, *W.YOLO_VARIANTS[variant], nc).forward(oy.preprocess(frames))
-    scaled = [(c - c.mean()) * (3.0 / c.std()) for c in cls]
-    top = np.concatenate([c.max(axis=-1).reshape(-1) for c in scaled])
-    shift = float(np.log(0.25 / 0.75) - np.quantile(top, 1.0 - frac))
-    for l in range(3):
-        w, b = state[f"model.22.cv2.{l}.2"]
-        state[f"model.22.cv2.{l}.2"] = ((w * (2.0 / box[l].std())).astype(np.float32), (b * 0).astype(np.float32))
-        w, b = state[f"model.22.cv3.{l}.2"]
-        sc = 3.0 / cls[l].std()
-        state[f"model.22.cv3.{l}.2"] = ((w * sc).astype(np.float32),
-                                        ((b - cls[l].mean()) * sc + shift).astype(np.float32))
-    return state
-
-
-def test_detect_end_to_end_vs_oracle(gpu):
-    frames = prng.synth_frames_bgr(21, 2, 240, 427)
-    state = _calibrated_state(frames)
-    det = D.Yolov8Detector("n", 80, state)
+@pytest.mark.parametrize("variant,nc,h,w,seed,min_stable", [
+    ("n", 80, 270, 480, 5, 20),     # objects (detect_objects' default model), bilinear letterbox
+    ("n", 1, 270, 480, 6, 20),      # faces: yolov8n-face, one class -> every candidate competes in NMS
+    ("n", 80, 1080, 1920, 5, 20),   # the reference's 1080p sources (scale 3 letterbox)
+    ("n", 1, 480, 854, 5, 20),      # BASELINE cfg1's 480p clip
+    ("m", 80, 1080, 1920, 6, 3),    # cfg4's object model: a deeper random net leaves fewer margin-decided detections
+])
+def test_detect_end_to_end_exact_on_margin_stable_detections(gpu, variant, nc, h, w, seed, min_stable):
+    """detect() end to end (letterbox -> network -> decode -> NMS -> scale_boxes) against the oracle, BASELINE's bar:
+    post-NMS indices exact.  Scope: the margin-stable detections of tests/wellcond.py, with the drift bounds MEASURED
+    in this run (oracle decode of the HIP head maps vs of the oracle head maps) and doubled.  Both directions: what
+    the oracle keeps stably the HIP path keeps, and what the HIP path keeps stably (judged on ITS maps) the oracle
+    keeps; same class; and the stable anchors appear in the same order on both sides."""
     conf = 0.25
+    frames = wellcond.blob_frames(seed, 1, h, w)
+    state = wellcond.calibrated_state(frames, variant, nc, seed=7, frac=0.08, conf=conf)
+    det = D.Yolov8Detector(variant, nc, state)
     dets, counts = det.detect(_dev(frames, gpu), conf=conf)
     dets_h, counts_h = det.detect(frames, conf=conf)  # host staging path gives the same bytes
     assert np.array_equal(counts, counts_h) and np.array_equal(dets, dets_h)
-    net = oy.Net(state, *W.YOLO_VARIANTS["n"], 80)
-    ref, (_, _, boxes, scores) = oy.detect(net, frames, conf)
-    # Network drift (HEAD_MAX) moves scores by ~1e-2 and boxes by a fraction of a pixel.  On smooth
-    # frames neighbouring anchors carry near-identical boxes and scores, so WHICH of them wins NMS
-    # is ill-conditioned; the detection it stands for is not.  Bar: every oracle detection with more
-    # conf margin than the drift has a HIP detection of the same class with IoU >= 0.7 (the NMS radius) and conf
-    # within 0.03, and vice versa, for at least 80 % of them (NMS chains near IoU 0.7 flip too).  (Exact index parity is asserted on identical head maps above.)
-    def iou(a, b):
-        iw = max(0.0, min(a[2], b[2]) - max(a[0], b[0]))
-        ih = max(0.0, min(a[3], b[3]) - max(a[1], b[1]))
-        u = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - iw * ih
-        return iw * ih / u if u > 0 else 0.0
-
-    for i in range(2):
-        got = [(np.array([dets[f][i, k] for f in ("x1", "y1", "x2", "y2")], dtype=np.float64),
-                float(dets["conf"][i, k]), int(dets["cls"][i, k])) for k in range(counts[i])]
-        want = [(d["xyxy"].astype(np.float64), d["conf"], d["cls"]) for d in ref[i]]
-        assert len(want) >= 5, "calibration should leave the oracle some detections"
-
-        def matched(x, pool):
-            return any(c == x[2] and iou(x[0], b) >= 0.7 and abs(s - x[1]) < 0.03 for b, s, c in pool)
-
-        sure_w = [x for x in want if x[1] > conf + 0.03]
-        sure_g = [x for x in got if x[1] > conf + 0.03]
-        assert sum(matched(x, got) for x in sure_w) >= 0.8 * len(sure_w), (len(sure_w), len(got))
-        assert sum(matched(x, want) for x in sure_g) >= 0.8 * len(sure_g), (len(sure_g), len(want))
+    net = oy.Net(state, *W.YOLO_VARIANTS[variant], nc)
+    ref, (_, _, boxes_o, scores_o) = oy.detect(net, frames, conf)
+    # the HIP side's own head maps, decoded by the oracle: its view of every anchor
+    x, plan = D.letterbox_f16(_dev(frames, gpu))
+    hb, hc = det.forward_raw(x)
+    boxes_g, scores_g = oy.decode([t.cpu().numpy() for t in hb], [t.cpu().numpy() for t in hc])
+    dc, du = wellcond.drift(boxes_o[0], scores_o[0], boxes_g[0], scores_g[0], conf)
+    assert dc < 0.03 and du < 0.08, (dc, du)  # the network tolerance (HEAD_MAX) seen through sigmoid / IoU
+    dc, du = 2 * dc + 1e-6, 2 * du + 1e-6
+    k = int(counts[0])
+    got = [int(a) for a in dets["anchor"][0, :k]]
+    got_cls = {int(a): int(c) for a, c in zip(dets["anchor"][0, :k], dets["cls"][0, :k])}
+    want = [d["anchor"] for d in ref[0]]
+    want_cls = {d["anchor"]: d["cls"] for d in ref[0]}
+    # the HIP path's post-processing of ITS maps is exactly the oracle's post-processing of those maps
+    ref_g = oy.non_max_suppression(boxes_g, scores_g, conf)
+    if wellcond.stably_kept(boxes_g[0], scores_g[0], [a for a, *_ in ref_g[0]], conf, 1e-6, 1e-5) == [a for a, *_ in ref_g[0]]:
+        assert got == [a for a, *_ in ref_g[0]]
+    stable_o = wellcond.stably_kept(boxes_o[0], scores_o[0], want, conf, dc, du)
+    stable_g = wellcond.stably_kept(boxes_g[0], scores_g[0], got, conf, dc, du)
+    assert len(stable_o) >= min_stable and len(stable_g) >= min_stable, (len(stable_o), len(stable_g), len(want), dc, du)
+    assert [a for a in stable_o if a not in got] == [], "a margin-stable oracle detection is missing from the HIP result"
+    assert [a for a in stable_g if a not in want] == [], "a margin-stable HIP detection is missing from the oracle result"
+    both = [a for a in stable_o if a in set(stable_g)]
+    assert all(got_cls[a] == want_cls[a] for a in both)
+    # order: anchors whose confidences differ by more than the drift keep their relative order
+    co = scores_o[0].max(1)
+    pos_g = {a: i for i, a in enumerate(got)}
+    pos_o = {a: i for i, a in enumerate(want)}
+    for i, a in enumerate(both):
+        for b in both[i + 1:]:
+            if abs(float(co[a]) - float(co[b])) > 2 * dc:
+                assert (pos_g[a] < pos_g[b]) == (pos_o[a] < pos_o[b]), (a, b)
+    # and their boxes / confidences agree to the drift (original-frame pixels)
+    for a in both:
+        d = next(x for x in ref[0] if x["anchor"] == a)
+        j = pos_g[a]
+        gb = np.array([dets[f][0, j] for f in ("x1", "y1", "x2", "y2")], np.float64)
+        assert abs(float(dets["conf"][0, j]) - d["conf"]) <= dc
+        assert np.abs(gb - d["xyxy"]).max() <= 0.02 * max(h, w)
     det.close()
+
+
+def test_lazy_and_dense_box_branch_give_identical_detections(gpu, tmp_path):
+    """detect() evaluates the box branch's 3x3 layers lazily (only around passing anchors) when the previous
+    call's pass rate was low, densely otherwise; the choice depends on history that arrives asynchronously.  Both
+    routes must produce the same bytes: force each in its own process (the switch is read once) on two consecutive
+    calls (the second call is the one that can go lazy) and compare."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from eioku_amd import detect as D, weights as W\n"
+        "from oracle import prng\n"
+        "f = torch.from_numpy(prng.synth_frames_bgr(41, 4, 240, 427)).cuda()\n"
+        "det = D.Yolov8Detector('n', 80, W.random_state('n', 80, seed=9))\n"
+        "det.calibrate_random_head(f, frac=0.01)\n"
+        "out = []\n"
+        "for _ in range(3):\n"
+        "    d, c = det.detect(f, conf=0.25)\n"
+        "    torch.cuda.synchronize()\n"
+        "    out += [d.view(np.uint8).reshape(len(c), -1)[i, :32 * c[i]] for i in range(len(c))] + [c]\n"
+        "np.savez(sys.argv[1], *out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    outs = {}
+    for frac in ("0", "0.5"):  # never lazy-deep / lazy-deep whenever <= 50 % of the anchors passed last time
+        path = tmp_path / f"dets_{frac}.npz"
+        subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=dict(os.environ, EIOKU_LAZY_DEEP_FRAC=frac),
+                       timeout=300)
+        with np.load(path) as z:
+            outs[frac] = [z[k] for k in z.files]
+    assert len(outs["0"]) == len(outs["0.5"]) and sum(int(a.size) for a in outs["0"]) > 15 * 32
+    for a, b in zip(outs["0"], outs["0.5"]):
+        assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("h,w", [(470, 640), (640, 470), (640, 472), (940, 1280), (1280, 940), (96, 160)])
@@ -282,15 +348,18 @@ def test_fused_3x3_1x1_pairs_are_bit_identical_to_separate_launches(gpu, variant
         assert a.dtype == np.float32 and np.array_equal(a, b)
 
 
-def test_full_size_batch_split_invariance_and_pipelined_order(gpu):
-    """BASELINE cfg2 size (64 x 640 x 640), size-independent properties: a frame's detections do not depend on
-    which frames share its batch (the flattened-pixel kernels cut tiles ACROSS frame borders, the persistent ones
-    walk tiles grid-stride over the whole batch), and PipelinedDetector (two handles, two streams) returns, in
-    submission order, exactly what the synchronous detector returns -- for device and host inputs."""
+@pytest.mark.parametrize("variant,h,w", [("n", 640, 640), ("m", 1080, 1920), ("n", 1080, 1920)])
+def test_full_size_batch_split_invariance_and_pipelined_order(gpu, variant, h, w):
+    """BASELINE cfg2 size (64 x 640 x 640, YOLOv8n) and cfg4's shape (64 x 1080p sources -> bilinear letterbox ->
+    YOLOv8m / YOLOv8n at 384 x 640), size-independent properties: a frame's detections do not depend on which frames
+    share its batch (the flattened-pixel kernels cut tiles ACROSS frame borders, the persistent ones walk tiles
+    grid-stride over the whole batch), detect() equals the unfused route K3 -> network -> K6/K7 byte for byte, and
+    PipelinedDetector (two handles, two streams) returns, in submission order, exactly what the synchronous detector
+    returns -- for device and host inputs."""
     import torch
 
-    frames = _dev(prng.synth_frames_bgr(77, 64, 640, 640), gpu)
-    det = D.Yolov8Detector("n", 80, W.random_state("n", 80, seed=5))
+    frames = _dev(prng.synth_frames_bgr(77, 64, h, w), gpu)
+    det = D.Yolov8Detector(variant, 80, W.random_state(variant, 80, seed=5))
     det.calibrate_random_head(frames[:8], frac=0.01)
     dets, counts = det.detect(frames, conf=0.25)
     assert counts.sum() > 64
@@ -299,6 +368,12 @@ def test_full_size_batch_split_invariance_and_pipelined_order(gpu):
         assert np.array_equal(c2, counts[lo:hi])
         for i in range(hi - lo):
             assert np.array_equal(d2[i, :c2[i]], dets[lo + i, :counts[lo + i]])
+    x, plan = D.letterbox_f16(frames[:8].contiguous())
+    assert (plan.out_h, plan.out_w) == ((640, 640) if h == 640 else (384, 640))
+    d3, c3 = D.postprocess(*det.forward_raw(x), plan, 0.25, 0.7, 300)
+    assert np.array_equal(c3, counts[:8])
+    for i in range(8):
+        assert np.array_equal(d3[i, :c3[i]], dets[i, :counts[i]])
     pipe = D.PipelinedDetector(det, depth=2)
     chunks = [(0, 16), (16, 48), (48, 64), (0, 64)]
     for k, (lo, hi) in enumerate(chunks):

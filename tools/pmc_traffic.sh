@@ -20,10 +20,13 @@ print(tot)
 PY
 )
 done
-python3 - "$OUT" "$KSUB" "$FWD" "${TOT[FETCH_SIZE]}" "${TOT[WRITE_SIZE]}" <<'PY'
+R=${GRAFT_REPO_ROOT:-/root/repo}
+python3 - "$OUT" "$KSUB" "$FWD" "${TOT[FETCH_SIZE]}" "${TOT[WRITE_SIZE]}" "$R" <<'PY'
 import json, sys
+sys.path.insert(0, sys.argv[6])
+import bench
 out, ksub, fwd, fetch_kib, write_kib = sys.argv[1], sys.argv[2], float(sys.argv[3]), float(sys.argv[4]), float(sys.argv[5])
-d = {"kernel_family": ksub, "forwards": fwd,
+d = {"kernel_family": ksub, "forwards": fwd, "csrc_sha16": bench.kernel_source_hash(),
      "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
      "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads), WRITE_SIZE as is; KiB -> bytes",
      "hbm_bytes_per_forward": (2.0 * fetch_kib + write_kib) * 1024.0 / fwd}
