@@ -59,7 +59,7 @@ def parse_args():
                     help="HIP-event kernel timing on every n-th timed step (0: off, -1: one step in the middle of the region)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU oracle sample budget")
     ap.add_argument("--no-1080p", action="store_true", help="skip the frames_1080p block")
-    ap.add_argument("--knn-mode", type=int, default=-1, help="scan_mode of the index (-1: library default)")
+    ap.add_argument("--knn-mode", type=int, default=-1, help="scan_mode of the index: 0 register-tile kernels, 1 scan path (-1: library default)")
     return ap.parse_args()
 
 
@@ -202,7 +202,7 @@ def knn_part(args, device, rank, world):
     ix = search.IndexFlatL2(d)
     if args.knn_mode >= 0:
         ix.set_param("scan_mode", args.knn_mode)
-    mode = args.knn_mode if args.knn_mode >= 0 else 2
+    mode = args.knn_mode if args.knn_mode >= 0 else 1
     ix.attach(xb)
     sh = search.ShardedFlatL2(ix, lo)
     sh.search(q, k)  # warm-up (allocates workspaces; the wide path builds its bf16 planes of the rows here: index build)
@@ -234,19 +234,17 @@ def knn_part(args, device, rank, world):
            "nq": args.knn_nq, "k": k, "ms_per_search": per * 1e3, "n_total": args.knn_n, "rows_per_gpu": hi - lo,
            "collective": "none" if world == 1 else "all_gather_into_tensor (RCCL) of nq*k*16 B per rank"}
     if scan:
-        terms = 3 if mode == 1 else 1
-        streamed = rows * d * 2 * (2 if terms == 3 else 1)  # bf16 hi (+ lo) plane, each read exactly once
-        out["dtype"] = ("f32 results: bf16 hi-plane filter with a rigorous margin on the matrix cores, exact fp32 re-rank of "
-                        "the candidates" if terms == 1 else "f32 results from split-bf16 products (3 MFMA terms), fp32 accumulate")
-        out["roofline"] = {"kernel": f"k_l2_scan (row tiles stationary in registers, {terms}-term bf16 MFMA, every query tile "
-                                     "streamed past them from L2; one HBM pass per search)",
+        streamed = rows * d * 2  # the bf16 plane of the rows, read exactly once
+        out["dtype"] = ("f32 results (sum (q-x)^2 over the fp32 rows of the candidates); candidates from a bf16 one-term filter "
+                        "with a rigorous margin on the matrix cores")
+        out["roofline"] = {"kernel": "k_l2_scan (row tiles stationary in registers, bf16 MFMA, every query tile streamed past "
+                                     "them from L2; one HBM pass per search)",
                            "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F16_PEAK_TFLOPS,
                            "achieved": flops / kernel_s / 1e12, "frac": flops / kernel_s / 1e12 / MFMA_F16_PEAK_TFLOPS,
-                           "mfma_bf16_TFLOPs_executed": terms * flops / kernel_s / 1e12,
                            "algorithmic_bytes_one_pass": one_pass, "algorithmic_GBps": one_pass / kernel_s / 1e9,
                            "hbm_bytes_streamed_per_launch": streamed, "hbm_GBps_streamed": streamed / kernel_s / 1e9,
                            "note": "achieved = SURVEY 8d's 2*nq*N*d over the scan kernel's HIP-event duration; the sample "
-                                   "search, candidate selection and merge launches are inside ms_per_search, not in it"}
+                                   "search, candidate binning / re-rank / selection launches are inside ms_per_search, not in it"}
     else:
         passes = (args.knn_nq + 31) // 32
         wide = args.knn_nq > 64

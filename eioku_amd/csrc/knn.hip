@@ -593,27 +593,31 @@ __global__ __launch_bounds__(64) void k_topk_merge(const float* pd, const int* p
 
 
 // ---------------------------------------------------------------------------------------------
-// Scan path (nq > 64, large N): database-tile stationary.
+// Scan path (nq > 64, large N): database tiles stationary in registers.
 //
 // The kernels above keep a 32-query tile in registers and stream the database past it, so a 1024-query
 // search reads the database 8 times (once per 128 queries).  Here the roles are swapped: a wave keeps a tile
-// of 32 database rows in registers as the MFMA A operand (pre-split bf16 planes, fragment-tiled at add/attach
+// of 32 database rows in registers as the MFMA A operand (a bf16 copy of the rows, fragment-tiled at add/attach
 // time so that a lane's fragment is one coalesced 16-byte load) and ALL query tiles stream past it through
-// LDS (LDS-DMA, one tile ahead; the query planes are 0.75-1.5 MB and live in every XCD's L2).  HBM sees each
-// plane exactly once per search and the kernel is bound by the bf16 matrix pipe.
+// LDS (LDS-DMA, one tile ahead; the query plane is <= 0.75 MB and lives in every XCD's L2).  HBM sees the bf16
+// plane exactly once per search (half the bytes of the fp32 rows) and the kernel is bound by the bf16 matrix pipe.
 //
 // A row-stationary wave meets every query, so per-query top-k lists cannot live in its registers.  Instead a
 // per-query upper bound tau_q on the k-th distance comes from an exact search of a strided SAMPLE of the rows
-// (the k-th best of any subset bounds the k-th best of the whole), the scan appends every (query, row) whose
-// distance is <= tau_q to that query's candidate list (expected k * N / S entries), and k_scan_select picks
-// the k best of each list.  A list that overflows raises a device flag and the launch of the old kernels
-// that follows - gated on that flag - recomputes the search (tested by forcing a tiny list).
+// (the k-th best of any subset bounds the k-th best of the whole), the scan keeps every (query, row) whose
+// distance may be <= tau_q (expected k * N / S pairs per query), k_scan_bin sorts them into per-query lists and
+// k_scan_select re-computes their distances in fp32 from the fp32 rows and picks the k best.  A list that
+// overflows raises a device flag and the launch of the register-tile kernels that follows - gated on that flag -
+// recomputes the search (tested by forcing tiny lists).
 //
-//   TERMS == 3: q.x ~ qh.xh + ql.xh + qh.xl (as k_flat_l2_bf), candidate distances are final.
-//   TERMS == 1: q.x ~ qh.xh only (one third of the matrix work, half of the HBM bytes).  |q.x - qh.xh| <=
-//               (2^-8 + 2^-18) sum|q_i x_i| <= 2^-8 (1 + 2^-9) |q| |x| for round-to-nearest bf16 operands, so the
-//               filter admits everything within that rigorous margin of tau_q and k_scan_select re-computes
-//               the candidates' distances in exact fp32 from the fp32 rows before selecting.
+// The products are ONE bf16 term, q.x ~ qh.xh (a third of the matrix work of the split-bf16 kernel above):
+// |q.x - qh.xh| <= (2^-8 + 2^-18) sum|q_i x_i| <= 2^-8 (1 + 2^-9) |q| |x| for round-to-nearest bf16 operands, so the
+// filter admits everything within that rigorous margin of tau_q; the distances that are returned never see bf16.
+//
+// Measured at 10 M x 384, nq 1024 (profiles/r02_knn_*): 7.4 ms for the scan = 1.06 PFLOP/s of algorithmic work;
+// ablation builds put the matrix-only floor of this structure at 4.85 ms, the filter at +1.5, the workgroup barrier
+// at +1.2, the query DMA at +1.15 and the LDS fragment reads at +0.7 (they add almost linearly: the 12 waves of a
+// workgroup run their phases in lockstep behind the one barrier per query tile).
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
@@ -624,18 +628,18 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f) {  // finite inputs
   return u >> 16;
 }
 
-// rows [n][D] fp32 -> fragment-tiled bf16 planes: unit ((tile * NS + s) * 2 + half) * 32 + r holds dims
-// 16 s + 8 half + [0, 8) of row 32 tile + r (the 32x32x16 A / B operand of lane 32 half + r).  hi = rne(x),
-// lo = rne(x - hi) (x - hi is exact).  Optional per-row half norms (0.5 |x|^2, +inf for rows >= n) and per-tile
-// max |x| (over valid rows).  Tiles [first_tile, first_tile + gridDim.x).
-template <int D>
+// rows [n][D] fp32 -> fragment-tiled bf16 plane: unit ((tile * NS + s) * 2 + half) * 32 + r holds dims
+// 16 s + 8 half + [0, 8) of row 32 tile + r (the 32x32x16 A / B operand of lane 32 half + r), rounded to nearest.
+// Optional per-row half norms (0.5 |x|^2, +inf for rows >= n) and per-tile max |x| (over valid rows).
+// Tiles [first_tile, first_tile + gridDim.x / SPLIT); SPLIT workgroups share a tile (few tiles: the queries).
+template <int D, int SPLIT>
 __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, long long n, long long first_tile,
                                                       const float* __restrict__ norms, u32x4k* __restrict__ hi,
-                                                      u32x4k* __restrict__ lo, float* __restrict__ hnorm,
-                                                      float* __restrict__ tmax) {
+                                                      float* __restrict__ hnorm, float* __restrict__ tmax) {
   constexpr int NS = D / 16, PU = NS * 64;
-  const long long tile = first_tile + blockIdx.x;
-  for (int o = threadIdx.x; o < PU; o += 256) {
+  const long long tile = first_tile + blockIdx.x / SPLIT;
+  const int part = blockIdx.x % SPLIT;
+  for (int o = part * (PU / SPLIT) + threadIdx.x; o < (part + 1) * (PU / SPLIT); o += 256) {
     const int s = o >> 6, h = (o >> 5) & 1, r = o & 31;
     const long long row = tile * 32 + r;
     float v[8];
@@ -647,16 +651,12 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
     }
-    unsigned hb[8], lb[8];
+    unsigned hb[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      hb[j] = bf16_rne_bits(v[j]);
-      lb[j] = bf16_rne_bits(v[j] - __uint_as_float(hb[j] << 16));
-    }
+    for (int j = 0; j < 8; ++j) hb[j] = bf16_rne_bits(v[j]);
     hi[(size_t)tile * PU + o] = u32x4k{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
-    if (lo) lo[(size_t)tile * PU + o] = u32x4k{lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16)};
   }
-  if (hnorm && threadIdx.x < 64) {
+  if (hnorm && part == 0 && threadIdx.x < 64) {
     const int r = threadIdx.x & 31;
     const long long row = tile * 32 + r;
     const float nn = row < n ? norms[row] : 0.f;
@@ -670,33 +670,38 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
 
 struct ScanArgs {
   const u32x4k* xh;      // [ntiles][NS*64] units
-  const u32x4k* xl;      // TERMS == 3
   const float* hnorm;    // [ntiles*32] 0.5 |x|^2, +inf beyond n
   const float* tmax;     // [ntiles] max |x| of the tile's valid rows
   const u32x4k* qh;      // [nqt][NS*64]
-  const u32x4k* ql;
   const float* qnorm;    // [nq]
   const float* tau;      // sample search result [nq][tau_k]; the bound is its last column
   int tau_k;
   long long n, ntiles;
   int nq, nqt;
-  float* cand_d;         // [nq][cap]
-  int* cand_i;           // [nq][cap] row ids
-  int* cnt;              // [nq]
-  int cap;
+  // candidates leave the scan as (query, row) pairs in a list private to the workgroup (an LDS counter hands out the
+  // slots: no global atomic, nothing to wait for); k_scan_bin sorts them into the per-query lists afterwards
+  unsigned* wl;          // [gridDim.x][wl_cap][2]
+  int* wl_cnt;           // [gridDim.x]
+  int wl_cap;
 };
 
-// NW waves per workgroup, each owning one 32-row tile (tile = wt * NW + wave); workgroups walk the WG tiles grid-stride.
-template <int D, int TERMS, int NW>
+// NW waves per workgroup, each owning RT 32-row tiles (tiles (wt * NW + wave) * RT + [0, RT)); workgroups walk the
+// workgroup tiles grid-stride.  Two staged query tiles: one in flight (LDS-DMA) while the other is multiplied.
+// RT = 2 feeds two MFMAs from every query fragment read (half the LDS bytes and half the L2 -> LDS query traffic per
+// product) at 2 x 96 operand registers: two waves per SIMD instead of three.
+template <int D, int NW, int RT>
 __global__ __launch_bounds__(NW * 64) void k_l2_scan(ScanArgs a) {
-  constexpr int NS = D / 16, PU = NS * 64;          // steps; 16-B units per tile and plane
-  constexpr int QBUF_U = PU * (TERMS == 3 ? 2 : 1);  // one staged query tile: [hi plane | lo plane]
+  constexpr int NS = D / 16, PU = NS * 64;  // steps; 16-B units per tile
+  constexpr int NDMA = (PU / 64 + NW - 1) / NW;  // LDS-DMA instructions per wave and query tile
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-  u32x4k* qbuf = reinterpret_cast<u32x4k*>(dyn_smem);                       // [2][QBUF_U]
-  float* s_hc = reinterpret_cast<float*>(dyn_smem + (size_t)2 * QBUF_U * 16);  // [nqt*32] 0.5 (|q|^2 - tau')
-  float* s_sq = s_hc + a.nqt * 32;                                            // [nqt*32] 2^-8-scaled |q| (TERMS == 1)
+  u32x4k* qbuf = reinterpret_cast<u32x4k*>(dyn_smem);                      // [2][PU]
+  float* s_hc = reinterpret_cast<float*>(dyn_smem + (size_t)2 * PU * 16);  // [nqt*32] 0.5 (|q|^2 - tau')
+  float* s_sq = s_hc + a.nqt * 32;                                         // [nqt*32] 2^-8-scaled |q|
+  float* s_hx = s_sq + a.nqt * 32;                                         // [NW*RT*32] 0.5 |x|^2 of each wave's rows
+  int* s_cnt = reinterpret_cast<int*>(s_hx + NW * RT * 32);                // slots handed out in this workgroup's list
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
 
   for (int q = tid; q < a.nqt * 32; q += NW * 64) {
@@ -704,142 +709,203 @@ __global__ __launch_bounds__(NW * 64) void k_l2_scan(ScanArgs a) {
     if (q < a.nq) {
       const float t = a.tau[(size_t)q * a.tau_k + (a.tau_k - 1)];
       const float qn = a.qnorm[q];
-      // slack: the sample's distances come from another kernel (other rounding of the same products)
+      // slack: the sample's distances come from another kernel (split-bf16 products, ~1e-6 absolute)
       hc = 0.5f * (qn - (t + 2e-5f * (1.0f + t)));
       sq = 0.00390625f * 1.002f * sqrtf(qn);  // 2^-8 (1 + 2^-9) |q|, rounded up
     }
     s_hc[q] = hc;
-    if (TERMS == 1) s_sq[q] = sq;
+    s_sq[q] = sq;
   }
+  if (tid == 0) *s_cnt = 0;
+  unsigned* const my_list = a.wl + (size_t)blockIdx.x * a.wl_cap * 2;
 
-  const long long nwt = (a.ntiles + NW - 1) / NW;
+  const long long nwt = (a.ntiles + NW * RT - 1) / (NW * RT);
+  // every wave issues exactly NDMA LDS-DMA instructions per query tile (pieces past the tile re-copy its last
+  // piece: same bytes, same place)
   auto stage_q = [&](int qt, int buf) {
 #pragma unroll
-    for (int u = wave * 64; u < PU; u += NW * 64) {  // wave-uniform LDS base, lane-linear 1 KiB pieces
+    for (int j = 0; j < NDMA; ++j) {
+      int u = (j * NW + wave) * 64;
+      if (u >= PU) u = PU - 64;
       __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(a.qh + (size_t)qt * PU + u + lane),
-                                       (lds_void_t*)(qbuf + (size_t)buf * QBUF_U + u), 16, 0, 0);
-      if (TERMS == 3)
-        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(a.ql + (size_t)qt * PU + u + lane),
-                                         (lds_void_t*)(qbuf + (size_t)buf * QBUF_U + PU + u), 16, 0, 0);
+                                       (lds_void_t*)(qbuf + (size_t)buf * PU + u), 16, 0, 0);
     }
   };
 
-  u32x4k xh[NS], xl[TERMS == 3 ? NS : 1];
-  float4 hx[4];  // 0.5 |x|^2 of rows 8 g + 4 half + {0..3}
-  float sxm = 0.f;
+  u32x4k xh[RT][NS];
+  float sxm[RT], hxmin[RT];  // each tile's max |x| and min 0.5 |x|^2 (wave-uniform)
   long long wt = blockIdx.x;
-  auto tile_of = [&](long long w) {
-    const long long t = w * NW + wave;
-    return t < a.ntiles ? t : a.ntiles - 1;  // clamped duplicates are masked through row0 below
+  auto tile_of = [&](long long w, int i) {
+    const long long t = (w * NW + wave) * RT + i;
+    return t < a.ntiles ? t : a.ntiles - 1;  // clamped duplicates are masked through `own` below
   };
+  // lanes 0..31 each read one row's half norm; the hot loop only needs the tile's minimum, the per-row values wait in
+  // LDS for the rare tile that may hold a candidate (16 registers less in the loop)
+  auto tile_min_hx = [&](long long t, int i) {
+    float m = a.hnorm[t * 32 + col];
+    if (half == 0) s_hx[(wave * RT + i) * 32 + col] = m;  // read back only by this wave: LDS operations of a wave stay in order
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+    return m;
+  };
+  // flat sequence of staged query tiles over all of this workgroup's row tiles: entry e is query tile e % nqt
+  const long long my_tiles = wt < nwt ? (nwt - 1 - wt) / gridDim.x + 1 : 0;
+  const int total = (int)(my_tiles * a.nqt);
   if (wt < nwt) {
-    const long long t = tile_of(wt);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      xh[s] = a.xh[(size_t)t * PU + s * 64 + lane];
-      if (TERMS == 3) xl[s] = a.xl[(size_t)t * PU + s * 64 + lane];
+    for (int i = 0; i < RT; ++i) {
+      const long long t = tile_of(wt, i);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) xh[i][s] = a.xh[(size_t)t * PU + s * 64 + lane];
+      sxm[i] = a.tmax[t];
+      hxmin[i] = tile_min_hx(t, i);
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) hx[g] = *reinterpret_cast<const float4*>(a.hnorm + t * 32 + 8 * g + 4 * half);
-    sxm = a.tmax[t];
+    // the first tile's operands are in registers before any LDS-DMA is issued: inside the loop the compiler must never
+    // find a reason to wait for "all vector memory" in the middle of the products
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_sched_barrier(0);
     stage_q(0, 0);
   }
-  int it = 0;  // staged query tiles so far: tile `it` lives in buffer it & 1
+  // Everything below is 32-bit and incremental: a 64-bit `% nqt` per iteration is a ~100-instruction scalar sequence
+  int it = 0;                     // entries consumed so far: entry `it` lives in buffer it & 1
+  int stage_qt = 1 % a.nqt;       // query tile of the next entry to stage
   for (; wt < nwt; wt += gridDim.x) {
-    const bool own = wt * NW + wave < a.ntiles;  // a clamped duplicate tile appends nothing
-    const long long row0 = tile_of(wt) * 32;
+    bool own[RT];
+    long long row0[RT], tn[RT];
     const long long nwt_next = wt + gridDim.x;
     const bool more_tiles = nwt_next < nwt;
-    const long long tn = more_tiles ? tile_of(nwt_next) : 0;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      own[i] = (wt * NW + wave) * RT + i < a.ntiles;  // a clamped duplicate tile appends nothing
+      row0[i] = tile_of(wt, i) * 32;
+      tn[i] = more_tiles ? tile_of(nwt_next, i) : 0;
+    }
     for (int qt = 0; qt < a.nqt; ++qt, ++it) {
       const bool last_qt = qt == a.nqt - 1;
-      // the staged tile has landed (this wave's pieces: vmcnt; everyone's: barrier) and every wave is done
-      // reading the other buffer (program order before the barrier)
+      // Entry `it` has landed (this wave's pieces: vmcnt; everyone's: the barrier) - and so have the operand registers
+      // refilled during the previous iteration - and every wave is done reading the other buffer, which the DMA issued
+      // below overwrites.  A raw s_barrier is not a memory fence to the optimiser (__syncthreads' fence would do, at the
+      // price of its own waits): the empty asm statements keep LDS reads from being hoisted across it, sched_barrier
+      // pins the machine order.
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-      __syncthreads();
-      if (!last_qt) stage_q(qt + 1, (it + 1) & 1);
-      else if (more_tiles) stage_q(0, (it + 1) & 1);
-      const u32x4k* qb = qbuf + (size_t)(it & 1) * QBUF_U;
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 1 < total) stage_q(stage_qt, (it + 1) & 1);
+      stage_qt = stage_qt + 1 == a.nqt ? 0 : stage_qt + 1;
+      const u32x4k* qb = qbuf + (size_t)(it & 1) * PU;
       const float hcq = s_hc[qt * 32 + col];
-      float thr_q = hcq;
-      if (TERMS == 1) thr_q = hcq - s_sq[qt * 32 + col] * sxm;
-      f32x16 acc;
+      const float sqq = s_sq[qt * 32 + col];
+      f32x16 acc[RT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
       // query fragments PF steps ahead of their MFMAs (a lone ds_read -> wait -> MFMA chain exposes the LDS latency)
-      constexpr int PF = 4;
-      u32x4k bh[PF], bl[TERMS == 3 ? PF : 1];
+      constexpr int PF = RT == 2 ? 2 : 4;
+      u32x4k bh[PF];
 #pragma unroll
-      for (int s = 0; s < PF; ++s) {
-        bh[s] = qb[s * 64 + lane];
-        if (TERMS == 3) bl[s] = qb[PU + s * 64 + lane];
-      }
+      for (int s = 0; s < PF; ++s) bh[s] = qb[s * 64 + lane];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const bf16x8 ch = __builtin_bit_cast(bf16x8, bh[s % PF]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xh[s]), ch, acc, 0, 0, 0);
-        if (TERMS == 3) {
-          const bf16x8 cl = __builtin_bit_cast(bf16x8, bl[s % PF]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xl[s]), ch, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xh[s]), cl, acc, 0, 0, 0);
-        }
-        if (s + PF < NS) {
-          bh[s % PF] = qb[(s + PF) * 64 + lane];
-          if (TERMS == 3) bl[s % PF] = qb[PU + (s + PF) * 64 + lane];
-        }
-        if (last_qt && more_tiles) {  // the next row tile replaces this one in place, step by step
-          xh[s] = a.xh[(size_t)tn * PU + s * 64 + lane];
-          if (TERMS == 3) xl[s] = a.xl[(size_t)tn * PU + s * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xh[i][s]), ch, acc[i], 0, 0, 0);
+        if (s + PF < NS) bh[s % PF] = qb[(s + PF) * 64 + lane];
+        if (last_qt && more_tiles) {
+          // The next row tile replaces this one IN PLACE, step by step: the load is inline assembly with the operand
+          // register as a read-write operand, so it lands in the very register the MFMA above just read (a plain
+          // assignment made the compiler keep a second set of 96 operand registers: one wave per SIMD fewer).  The
+          // compiler does not know these registers are pending: the vmcnt(0) + sched_barrier at the top of the next
+          // iteration stands between the loads and their first use.  Address = wave-uniform SGPR base (tile, 4 KiB group
+          // of steps) + lane * 16 in one VGPR + immediate: no per-step 64-bit address registers live across the loop.
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(a.xh) + ((size_t)tn[i] * PU + (s & ~3) * 64) * 16;
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(xh[i][s]) : "v"(lane * 16), "s"(base), "n"((s & 3) * 1024));
+          }
         }
       }
       if (!last_qt) {  // pin the issue order of the steady-state body: PF reads ahead, then MFMAs and reads alternate
-        __builtin_amdgcn_sched_group_barrier(0x100, PF * (TERMS == 3 ? 2 : 1), 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          __builtin_amdgcn_sched_group_barrier(0x008, TERMS, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 2 : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, RT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
       }
-      // filter: dist <= tau'  <=>  acc >= 0.5 |x|^2 + 0.5 (|q|^2 - tau')   (minus the TERMS == 1 margin)
-      bool any = false;
+      // filter: dist <= tau'  <=>  product >= 0.5 |x|^2 + 0.5 (|q|^2 - tau') - margin.  First the tile's largest product
+      // against the tile's smallest row norm (8 max3 + one compare for 16 products); the per-row test runs only in the
+      // rare tile that may hold a candidate.
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float hxr = r & 2 ? (r & 1 ? hx[r >> 2].w : hx[r >> 2].z) : (r & 1 ? hx[r >> 2].y : hx[r >> 2].x);
-        any |= acc[r] >= hxr + thr_q;
-      }
-      if (any && own) {
-        const int qi = qt * 32 + col;
-        const float qn = a.qnorm[qi < a.nq ? qi : 0];
+      for (int i = 0; i < RT; ++i) {
+        const f32x16& c = acc[i];
+        const float thr_q = hcq - sqq * sxm[i];
+        float m01 = fmaxf(fmaxf(c[0], c[1]), c[2]), m23 = fmaxf(fmaxf(c[3], c[4]), c[5]);
+        float m45 = fmaxf(fmaxf(c[6], c[7]), c[8]), m67 = fmaxf(fmaxf(c[9], c[10]), c[11]);
+        float m89 = fmaxf(fmaxf(c[12], c[13]), c[14]);
+        const float mx = fmaxf(fmaxf(fmaxf(m01, m23), fmaxf(m45, m67)), fmaxf(m89, c[15]));
+        if (mx >= hxmin[i] + thr_q && own[i]) {
+          const int qi = qt * 32 + col;
+          int h4 = 4 * half;
+          asm volatile("" : "+v"(h4));  // keeps the 16 row offsets from being precomputed into registers that live across the loop
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float hxr = r & 2 ? (r & 1 ? hx[r >> 2].w : hx[r >> 2].z) : (r & 1 ? hx[r >> 2].y : hx[r >> 2].x);
-          if (acc[r] >= hxr + thr_q) {
-            float dist = (qn + 2.0f * hxr) - 2.0f * acc[r];
-            dist = dist < 0.f ? 0.f : dist;
-            const int pos = atomicAdd(a.cnt + qi, 1);
-            if (pos < a.cap) {
-              a.cand_d[(size_t)qi * a.cap + pos] = dist;
-              a.cand_i[(size_t)qi * a.cap + pos] = (int)(row0 + (r & 3) + 8 * (r >> 2) + 4 * half);
+          for (int g = 0; g < 4; ++g) {
+            const float4 hx = *reinterpret_cast<const float4*>(s_hx + (wave * RT + i) * 32 + 8 * g + h4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float hxr = j == 0 ? hx.x : (j == 1 ? hx.y : (j == 2 ? hx.z : hx.w));
+              if (c[4 * g + j] >= hxr + thr_q) {
+                const int pos = atomicAdd(s_cnt, 1);  // LDS
+                if (pos < a.wl_cap) {
+                  my_list[2 * (size_t)pos] = (unsigned)qi;
+                  my_list[2 * (size_t)pos + 1] = (unsigned)((int)row0[i] + 8 * g + j + h4);
+                }
+              }
             }
           }
         }
       }
       if (last_qt && more_tiles) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) hx[g] = *reinterpret_cast<const float4*>(a.hnorm + tn * 32 + 8 * g + 4 * half);
-        sxm = a.tmax[tn];
+        for (int i = 0; i < RT; ++i) {
+          sxm[i] = a.tmax[tn[i]];
+          hxmin[i] = tile_min_hx(tn[i], i);
+        }
       }
     }
   }
+  __syncthreads();
+  if (tid == 0) a.wl_cnt[blockIdx.x] = *s_cnt;
 }
 
-// One workgroup per query: (TERMS == 1: exact fp32 distances of the candidates,) then the k best by (dist, id).
-template <int D, int TERMS>
-__global__ __launch_bounds__(256) void k_scan_select(const float* __restrict__ db, const float* __restrict__ dbnorm,
-                                                     const float* __restrict__ q, const float* __restrict__ qnorm,
-                                                     const float* __restrict__ cand_d, const int* __restrict__ cand_i,
-                                                     const int* __restrict__ cnt, int cap, int k, float* __restrict__ Dout,
-                                                     long long* __restrict__ Iout, int* __restrict__ overflow) {
+// (query, row) pairs of the scan's workgroup lists -> per-query candidate lists.  One workgroup per list.
+__global__ __launch_bounds__(256) void k_scan_bin(const unsigned* __restrict__ wl, const int* __restrict__ wl_cnt, int wl_cap,
+                                                  int* __restrict__ cand_i, int* __restrict__ cnt, int cap,
+                                                  int* __restrict__ overflow) {
+  int c = wl_cnt[blockIdx.x];
+  if (c > wl_cap) {
+    if (threadIdx.x == 0) atomicOr(overflow, 1);
+    c = wl_cap;
+  }
+  const unsigned* list = wl + (size_t)blockIdx.x * wl_cap * 2;
+  for (int i = threadIdx.x; i < c; i += 256) {
+    const int qi = (int)list[2 * i], row = (int)list[2 * i + 1];
+    const int pos = atomicAdd(cnt + qi, 1);
+    if (pos < cap) cand_i[(size_t)qi * cap + pos] = row;
+  }
+}
+
+// One workgroup per query: fp32 distances of its candidates, sum (q_i - x_i)^2 from the fp32 rows (no
+// |q|^2 + |x|^2 - 2 q.x cancellation: an exact copy of the query scores exactly 0), then the k best by (dist, id).
+template <int D>
+__global__ __launch_bounds__(256) void k_scan_select(const float* __restrict__ db, const float* __restrict__ q,
+                                                     const int* __restrict__ cand_i, const int* __restrict__ cnt, int cap, int k,
+                                                     float* __restrict__ Dout, long long* __restrict__ Iout,
+                                                     int* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   float* sd = reinterpret_cast<float*>(dyn_smem);  // [cap]
   int* si = reinterpret_cast<int*>(sd + cap);      // [cap]
@@ -852,46 +918,38 @@ __global__ __launch_bounds__(256) void k_scan_select(const float* __restrict__ d
     c = cap;
   }
   for (int j = tid; j < c; j += 256) si[j] = cand_i[(size_t)qi * cap + j];
-  if (TERMS == 3) {
-    for (int j = tid; j < c; j += 256) sd[j] = cand_d[(size_t)qi * cap + j];
-  } else {
-    // a half wave per candidate: lane l of 32 owns dims 4 l + 128 t + [0, 4)
-    constexpr int NV = D / 128;
+  __syncthreads();
+  {
+    // a half wave per candidate, four candidates in flight: lane l of 32 owns dims 4 l + 128 t + [0, 4)
+    constexpr int NV = D / 128, U = 4;
     const int l32 = lane & 31, hw = tid >> 5;
     float4 qv[NV];
 #pragma unroll
     for (int t = 0; t < NV; ++t) qv[t] = *reinterpret_cast<const float4*>(q + (size_t)qi * D + 128 * t + 4 * l32);
-    const float qn = qnorm[qi];
-    for (int j0 = hw; j0 < c; j0 += 16) {
-      const int j1 = j0 + 8;
-      const int r0 = cand_i[(size_t)qi * cap + j0];
-      const int r1 = cand_i[(size_t)qi * cap + (j1 < c ? j1 : j0)];
-      float4 x0[NV], x1[NV];
+    for (int j0 = hw; j0 < c; j0 += 8 * U) {
+      float4 xv[U][NV];
 #pragma unroll
-      for (int t = 0; t < NV; ++t) {
-        x0[t] = *reinterpret_cast<const float4*>(db + (size_t)r0 * D + 128 * t + 4 * l32);
-        x1[t] = *reinterpret_cast<const float4*>(db + (size_t)r1 * D + 128 * t + 4 * l32);
-      }
-      float s0 = 0.f, s1 = 0.f;
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + 8 * u;
+        const int r = si[j < c ? j : j0];
 #pragma unroll
-      for (int t = 0; t < NV; ++t) {
-        s0 = fmaf(qv[t].x, x0[t].x, s0); s0 = fmaf(qv[t].y, x0[t].y, s0);
-        s0 = fmaf(qv[t].z, x0[t].z, s0); s0 = fmaf(qv[t].w, x0[t].w, s0);
-        s1 = fmaf(qv[t].x, x1[t].x, s1); s1 = fmaf(qv[t].y, x1[t].y, s1);
-        s1 = fmaf(qv[t].z, x1[t].z, s1); s1 = fmaf(qv[t].w, x1[t].w, s1);
+        for (int t = 0; t < NV; ++t) xv[u][t] = *reinterpret_cast<const float4*>(db + (size_t)r * D + 128 * t + 4 * l32);
       }
 #pragma unroll
-      for (int off = 16; off > 0; off >>= 1) {
-        s0 += __shfl_xor(s0, off, 64);
-        s1 += __shfl_xor(s1, off, 64);
-      }
-      if (l32 == 0) {
-        float d0 = (qn + dbnorm[r0]) - 2.0f * s0;
-        sd[j0] = d0 < 0.f ? 0.f : d0;
-        if (j1 < c) {
-          float d1 = (qn + dbnorm[r1]) - 2.0f * s1;
-          sd[j1] = d1 < 0.f ? 0.f : d1;
+      for (int u = 0; u < U; ++u) {
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+          float e;
+          e = qv[t].x - xv[u][t].x; sum = fmaf(e, e, sum);
+          e = qv[t].y - xv[u][t].y; sum = fmaf(e, e, sum);
+          e = qv[t].z - xv[u][t].z; sum = fmaf(e, e, sum);
+          e = qv[t].w - xv[u][t].w; sum = fmaf(e, e, sum);
         }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const int j = j0 + 8 * u;
+        if (l32 == 0 && j < c) sd[j] = sum;
       }
     }
   }
@@ -962,27 +1020,24 @@ struct eioku_index {
   int* pi = nullptr; size_t picap = 0;
   float* dout = nullptr; size_t dcap = 0;
   long long* iout = nullptr; size_t icap = 0;
-  // scan path (see k_l2_scan): fragment-tiled bf16 planes of the rows, built lazily and extended on add()
+  // scan path (see k_l2_scan): fragment-tiled bf16 plane of the rows, built lazily and extended on add()
   unsigned char* xh = nullptr; size_t xhcap = 0;
-  unsigned char* xl = nullptr; size_t xlcap = 0;
   float* hnorm = nullptr; size_t hncap = 0;
   float* tmax = nullptr; size_t tmcap = 0;
-  long long planes_n = 0;      // rows covered by the planes
-  bool planes_lo = false;      // lo plane present
+  long long planes_n = 0;      // rows covered by the plane
   unsigned char* qh = nullptr; size_t qhcap = 0;
-  unsigned char* ql = nullptr; size_t qlcap = 0;
+  unsigned* wl = nullptr; size_t wlcap = 0;
+  int* wl_cnt = nullptr; size_t wlccap = 0;
   float* tau = nullptr; size_t taucap = 0;
   long long* tau_i = nullptr; size_t tauicap = 0;
-  float* cand_d = nullptr; size_t cdcap = 0;
   int* cand_i = nullptr; size_t cicap = 0;
   int* cnt = nullptr; size_t cntcap = 0;  // [nq] counters + 1 overflow word
   // parameters (eioku_index_set_param)
-  int scan_mode = 2;           // 0: off; 1: three-term products; 2: one-term filter + exact fp32 re-rank
-  int scan_cap = 8192;         // candidate slots per query
+  int scan_mode = 1;           // 0: register-tile kernels only; 1: scan path for wide searches over large indexes
+  int scan_cap = 4096;         // candidate slots per query
   long long scan_min_rows = 262144;
   long long scan_sample = 0;   // sample rows for the bound (0: automatic)
-  int scan_waves = 0;          // waves per scan workgroup (0: automatic)
-  int last_overflow_checked = 0;
+  int scan_rt = 1;             // row tiles per wave: 1 (12 waves per workgroup) or 2 (8 waves)
 };
 
 namespace {
@@ -1058,8 +1113,8 @@ void eioku_index_destroy(eioku_index* ix) {
   if (!ix) return;
   (void)hipDeviceSynchronize();
   if (ix->x && !ix->attached) (void)hipFree(ix->x);
-  void* bufs[] = {ix->norms, ix->qbuf, ix->qnorm, ix->pd, ix->pi, ix->dout, ix->iout, ix->xh, ix->xl, ix->hnorm,
-                  ix->tmax, ix->qh, ix->ql, ix->tau, ix->tau_i, ix->cand_d, ix->cand_i, ix->cnt};
+  void* bufs[] = {ix->norms, ix->qbuf, ix->qnorm, ix->pd, ix->pi, ix->dout, ix->iout, ix->xh, ix->hnorm,
+                  ix->tmax, ix->qh, ix->wl, ix->wl_cnt, ix->tau, ix->tau_i, ix->cand_i, ix->cnt};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete ix;
@@ -1224,28 +1279,32 @@ int legacy_search(eioku_index* ix, const float* dq, int nq, int k, const float* 
   return EIOKU_OK;
 }
 
-template <int D>
-int launch_split(const float* x, long long n, long long first_tile, long long tiles, const float* norms, void* hi,
-                 void* lo, float* hnorm, float* tmax, hipStream_t stream) {
+int split_planes(int d, const float* x, long long n, long long first_tile, long long tiles, const float* norms, void* hi,
+                 float* hnorm, float* tmax, bool few_tiles, hipStream_t stream) {
   if (tiles <= 0) return EIOKU_OK;
-  hipLaunchKernelGGL((k_split_planes<D>), dim3((unsigned)tiles), dim3(256), 0, stream, x, n, first_tile, norms,
-                     (u32x4k*)hi, (u32x4k*)lo, hnorm, tmax);
+#define EIOKU_SPLIT(D_)                                                                                                  \
+  case D_:                                                                                                               \
+    if (few_tiles)                                                                                                       \
+      hipLaunchKernelGGL((k_split_planes<D_, 8>), dim3((unsigned)tiles * 8), dim3(256), 0, stream, x, n, first_tile, norms, \
+                         (u32x4k*)hi, hnorm, tmax);                                                                      \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((k_split_planes<D_, 1>), dim3((unsigned)tiles), dim3(256), 0, stream, x, n, first_tile, norms,   \
+                         (u32x4k*)hi, hnorm, tmax);                                                                      \
+    break;
+  switch (d) {
+    EIOKU_SPLIT(128)
+    EIOKU_SPLIT(256)
+    EIOKU_SPLIT(384)
+    default:
+      set_error("scan path: dimension %d not supported", d);
+      return EIOKU_EINVAL;
+  }
+#undef EIOKU_SPLIT
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }
 
-int split_planes(int d, const float* x, long long n, long long first_tile, long long tiles, const float* norms,
-                 void* hi, void* lo, float* hnorm, float* tmax, hipStream_t stream) {
-  switch (d) {
-    case 128: return launch_split<128>(x, n, first_tile, tiles, norms, hi, lo, hnorm, tmax, stream);
-    case 256: return launch_split<256>(x, n, first_tile, tiles, norms, hi, lo, hnorm, tmax, stream);
-    case 384: return launch_split<384>(x, n, first_tile, tiles, norms, hi, lo, hnorm, tmax, stream);
-  }
-  set_error("scan path: dimension %d not supported", d);
-  return EIOKU_EINVAL;
-}
-
-// a buffer that keeps its contents when it grows (the planes are extended on add())
+// a buffer that keeps its contents when it grows (the plane is extended on add())
 template <typename T>
 int grow_keep(T** p, size_t* cap, size_t bytes, size_t keep, hipStream_t stream) {
   if (*cap >= bytes) return EIOKU_OK;
@@ -1264,70 +1323,64 @@ int grow_keep(T** p, size_t* cap, size_t bytes, size_t keep, hipStream_t stream)
   return EIOKU_OK;
 }
 
-int ensure_planes(eioku_index* ix, bool need_lo, hipStream_t stream) {
+int ensure_planes(eioku_index* ix, hipStream_t stream) {
   const int d = ix->d;
-  const size_t tile_b = (size_t)d * 32 * 2;  // bytes per 32-row tile and plane
+  const size_t tile_b = (size_t)d * 32 * 2;  // bytes per 32-row tile
   const long long ntiles = (ix->n + 31) / 32;
-  if (need_lo && !ix->planes_lo) ix->planes_n = 0;  // the lo plane was never built: start over
-  const long long keep_tiles = ix->planes_n / 32;    // complete tiles stay valid
+  const long long keep_tiles = ix->planes_n / 32;  // complete tiles stay valid
   int rc = grow_keep(&ix->xh, &ix->xhcap, (size_t)ntiles * tile_b, (size_t)keep_tiles * tile_b, stream);
   if (rc) return rc;
-  if (need_lo || ix->planes_lo) {
-    rc = grow_keep(&ix->xl, &ix->xlcap, (size_t)ntiles * tile_b, (size_t)keep_tiles * tile_b, stream);
-    if (rc) return rc;
-  }
   rc = grow_keep(&ix->hnorm, &ix->hncap, (size_t)ntiles * 32 * sizeof(float), (size_t)keep_tiles * 32 * sizeof(float), stream);
   if (rc) return rc;
   rc = grow_keep(&ix->tmax, &ix->tmcap, (size_t)ntiles * sizeof(float), (size_t)keep_tiles * sizeof(float), stream);
   if (rc) return rc;
   if (ix->planes_n != ix->n) {
-    const bool lo = need_lo || ix->planes_lo;
-    rc = split_planes(d, ix->x, ix->n, keep_tiles, ntiles - keep_tiles, ix->norms, ix->xh, lo ? ix->xl : nullptr,
-                      ix->hnorm, ix->tmax, stream);
+    rc = split_planes(d, ix->x, ix->n, keep_tiles, ntiles - keep_tiles, ix->norms, ix->xh, ix->hnorm, ix->tmax, false, stream);
     if (rc) return rc;
-    ix->planes_lo = lo;
     ix->planes_n = ix->n;
   }
   return EIOKU_OK;
 }
 
-template <int D, int TERMS>
-int launch_scan(const eioku_index* ix, const ScanArgs& a, int nw, hipStream_t stream) {
+template <int D>
+int launch_scan(eioku_index* ix, ScanArgs& a, int rt, long long* grid_out, hipStream_t stream) {
   constexpr int PU = (D / 16) * 64;
-  const size_t lds = (size_t)2 * PU * (TERMS == 3 ? 2 : 1) * 16 + (size_t)a.nqt * 32 * 4 * 2;
-  const long long nwt = (a.ntiles + nw - 1) / nw;
-  // co-resident workgroups per CU: LDS (160 KiB) and 2048 threads
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 2048 / (nw * 64)) per_cu = 2048 / (nw * 64);
-  if (per_cu < 1) per_cu = 1;
-  if (TERMS == 3 && per_cu > 1) per_cu = 1;  // the 3-term kernel holds 192 operand registers: one wave per SIMD
-  long long grid = (long long)num_cus() * per_cu;
+  const int nw = rt == 2 ? 8 : 12;
+  const size_t lds = (size_t)2 * PU * 16 + (size_t)a.nqt * 32 * 4 * 2 + (size_t)nw * rt * 32 * 4 + 16;
+  const long long nwt = (a.ntiles + (long long)nw * rt - 1) / ((long long)nw * rt);
+  // one workgroup per CU: its 12 (8) waves are the three (two) per SIMD that 96 (192) operand registers allow
+  long long grid = num_cus();
   if (grid > nwt) grid = nwt;
-#define EIOKU_SCAN_LAUNCH(NW_)                                                                              \
-  do {                                                                                                      \
-    EIOKU_HIP_CHECK(hipFuncSetAttribute((const void*)k_l2_scan<D, TERMS, NW_>,                              \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-    hipLaunchKernelGGL((k_l2_scan<D, TERMS, NW_>), dim3((unsigned)grid), dim3(NW_ * 64), lds, stream, a);   \
-  } while (0)
-  if (nw == 4) EIOKU_SCAN_LAUNCH(4);
-  else if (nw == 8) EIOKU_SCAN_LAUNCH(8);
-  else {
-    set_error("scan_waves must be 4 or 8");
-    return EIOKU_EINVAL;
+  // workgroup lists: 64 MB of pairs shared out evenly (expected use: k N / sample rows per query in total)
+  long long wl_cap = ((64ll << 20) / 8) / grid;
+  if (wl_cap > (1 << 20)) wl_cap = 1 << 20;
+  if (ix->scan_cap < 256) wl_cap = ix->scan_cap;  // tests shrink both kinds of list to force the overflow paths
+  int rc = grow(&ix->wl, &ix->wlcap, (size_t)grid * wl_cap * 8);
+  if (rc) return rc;
+  rc = grow(&ix->wl_cnt, &ix->wlccap, (size_t)grid * sizeof(int));
+  if (rc) return rc;
+  a.wl = ix->wl;
+  a.wl_cnt = ix->wl_cnt;
+  a.wl_cap = (int)wl_cap;
+  *grid_out = grid;
+  if (rt == 2) {
+    EIOKU_HIP_CHECK(hipFuncSetAttribute((const void*)k_l2_scan<D, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_l2_scan<D, 8, 2>), dim3((unsigned)grid), dim3(8 * 64), lds, stream, a);
+  } else {
+    EIOKU_HIP_CHECK(hipFuncSetAttribute((const void*)k_l2_scan<D, 12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_l2_scan<D, 12, 1>), dim3((unsigned)grid), dim3(12 * 64), lds, stream, a);
   }
-#undef EIOKU_SCAN_LAUNCH
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }
 
-template <int D, int TERMS>
+template <int D>
 int launch_select(const eioku_index* ix, const float* dq, int nq, int cap, int k, float* dD, long long* dI, int* overflow,
                   hipStream_t stream) {
   const size_t lds = (size_t)cap * 8;
-  EIOKU_HIP_CHECK(hipFuncSetAttribute((const void*)k_scan_select<D, TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
-  hipLaunchKernelGGL((k_scan_select<D, TERMS>), dim3(nq), dim3(256), lds, stream, ix->x, ix->norms, dq, ix->qnorm,
-                     ix->cand_d, ix->cand_i, ix->cnt, cap, k, dD, dI, overflow);
+  EIOKU_HIP_CHECK(hipFuncSetAttribute((const void*)k_scan_select<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_scan_select<D>), dim3(nq), dim3(256), lds, stream, ix->x, dq, ix->cand_i, ix->cnt, cap, k, dD, dI,
+                     overflow);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
 }
@@ -1335,46 +1388,44 @@ int launch_select(const eioku_index* ix, const float* dq, int nq, int cap, int k
 // nq <= 1024 device queries through the scan path; qnorm already holds their norms
 int scan_search(eioku_index* ix, const float* dq, int nq, int k, float* dD, long long* dI, hipStream_t stream) {
   const int d = ix->d;
-  const int terms = ix->scan_mode == 1 ? 3 : 1;
-  int rc = ensure_planes(ix, terms == 3, stream);
+  int rc = ensure_planes(ix, stream);
   if (rc) return rc;
   const int nqt = (nq + 31) / 32;
-  const size_t qplane = (size_t)nqt * d * 32 * 2;
-  rc = grow(&ix->qh, &ix->qhcap, qplane);
-  if (rc) return rc;
-  rc = grow(&ix->ql, &ix->qlcap, qplane);
+  rc = grow(&ix->qh, &ix->qhcap, (size_t)nqt * d * 32 * 2);
   if (rc) return rc;
   rc = grow(&ix->tau, &ix->taucap, (size_t)nq * k * sizeof(float));
   if (rc) return rc;
   rc = grow(&ix->tau_i, &ix->tauicap, (size_t)nq * k * sizeof(long long));
   if (rc) return rc;
   const int cap = ix->scan_cap;
-  rc = grow(&ix->cand_d, &ix->cdcap, (size_t)nq * cap * sizeof(float));
-  if (rc) return rc;
   rc = grow(&ix->cand_i, &ix->cicap, (size_t)nq * cap * sizeof(int));
   if (rc) return rc;
   rc = grow(&ix->cnt, &ix->cntcap, ((size_t)nq + 1) * sizeof(int));
   if (rc) return rc;
   int* overflow = ix->cnt + nq;
   EIOKU_HIP_CHECK(hipMemsetAsync(ix->cnt, 0, ((size_t)nq + 1) * sizeof(int), stream));
-  rc = split_planes(d, dq, nq, 0, nqt, nullptr, ix->qh, terms == 3 ? ix->ql : nullptr, nullptr, nullptr, stream);
+  rc = split_planes(d, dq, nq, 0, nqt, nullptr, ix->qh, nullptr, nullptr, true, stream);
   if (rc) return rc;
-  // bound: exact search of a strided sample (k-th best of a subset >= k-th best of the whole)
+  // bound: exact search of a strided sample (k-th best of a subset >= k-th best of the whole): N / 128 rows, in
+  // slabs long enough to amortise each workgroup's 128-query operand load
   long long sample = ix->scan_sample > 0 ? ix->scan_sample : ix->n / 128;
   if (sample < 32768) sample = 32768;
   if (sample > 262144) sample = 262144;
-  const long long srows = 512;
-  int sslabs = (int)(sample / srows);
-  if ((long long)sslabs * srows * 2 > ix->n) sslabs = (int)(ix->n / (2 * srows));
+  // exactly one round of workgroups on the chip: (query groups of 128) x slabs <= CUs - every workgroup of that kernel
+  // pays ~50 us to load and split its 128-query operand before it sees a row
+  const int ygroups = (nq + 127) / 128;
+  int sslabs = num_cus() / ygroups;
+  if (sslabs < 1) sslabs = 1;
+  long long srows = ((sample / sslabs + 127) / 128) * 128;
+  if (srows < 512) srows = 512;
+  while (sslabs > 1 && (long long)sslabs * srows * 2 > ix->n) --sslabs;
   rc = legacy_search(ix, dq, nq, k, nullptr, nullptr, ix->tau, ix->tau_i, nullptr, sslabs, srows, false, stream);
   if (rc) return rc;
   ScanArgs a;
   a.xh = (const u32x4k*)ix->xh;
-  a.xl = (const u32x4k*)ix->xl;
   a.hnorm = ix->hnorm;
   a.tmax = ix->tmax;
   a.qh = (const u32x4k*)ix->qh;
-  a.ql = (const u32x4k*)ix->ql;
   a.qnorm = ix->qnorm;
   a.tau = ix->tau;
   a.tau_k = k;
@@ -1382,38 +1433,25 @@ int scan_search(eioku_index* ix, const float* dq, int nq, int k, float* dD, long
   a.ntiles = (ix->n + 31) / 32;
   a.nq = nq;
   a.nqt = nqt;
-  a.cand_d = ix->cand_d;
-  a.cand_i = ix->cand_i;
-  a.cnt = ix->cnt;
-  a.cap = cap;
-  const int nw = ix->scan_waves ? ix->scan_waves : (terms == 3 ? 4 : 8);
+  long long sgrid = 0;
   prof_start(EIOKU_PROF_KNN, stream);
-  rc = -1;
-#define EIOKU_SCAN_CASE(D_)                                                                    \
-  case D_:                                                                                     \
-    rc = terms == 3 ? launch_scan<D_, 3>(ix, a, nw, stream) : launch_scan<D_, 1>(ix, a, nw, stream); \
-    break;
   switch (d) {
-    EIOKU_SCAN_CASE(128)
-    EIOKU_SCAN_CASE(256)
-    EIOKU_SCAN_CASE(384)
+    case 128: rc = launch_scan<128>(ix, a, ix->scan_rt, &sgrid, stream); break;
+    case 256: rc = launch_scan<256>(ix, a, ix->scan_rt, &sgrid, stream); break;
+    default: rc = launch_scan<384>(ix, a, ix->scan_rt, &sgrid, stream); break;
   }
-#undef EIOKU_SCAN_CASE
   prof_stop(EIOKU_PROF_KNN, stream);
   if (rc) return rc;
-#define EIOKU_SEL_CASE(D_)                                                                                  \
-  case D_:                                                                                                  \
-    rc = terms == 3 ? launch_select<D_, 3>(ix, dq, nq, cap, k, dD, dI, overflow, stream)                    \
-                    : launch_select<D_, 1>(ix, dq, nq, cap, k, dD, dI, overflow, stream);                   \
-    break;
+  hipLaunchKernelGGL(k_scan_bin, dim3((unsigned)sgrid), dim3(256), 0, stream, ix->wl, ix->wl_cnt, a.wl_cap, ix->cand_i, ix->cnt,
+                     cap, overflow);
+  EIOKU_LAUNCH_CHECK();
   switch (d) {
-    EIOKU_SEL_CASE(128)
-    EIOKU_SEL_CASE(256)
-    EIOKU_SEL_CASE(384)
+    case 128: rc = launch_select<128>(ix, dq, nq, cap, k, dD, dI, overflow, stream); break;
+    case 256: rc = launch_select<256>(ix, dq, nq, cap, k, dD, dI, overflow, stream); break;
+    default: rc = launch_select<384>(ix, dq, nq, cap, k, dD, dI, overflow, stream); break;
   }
-#undef EIOKU_SEL_CASE
   if (rc) return rc;
-  // a candidate list overflowed (adversarial data for the sample bound): the gated register-tile search redoes it
+  // a list overflowed (adversarial data for the sample bound): the gated register-tile search redoes the group
   return legacy_search(ix, dq, nq, k, nullptr, nullptr, dD, dI, overflow, 0, 0, false, stream);
 }
 
@@ -1507,7 +1545,7 @@ int eioku_index_search_after(eioku_index* ix, const float* q, int nq, int k, con
 int eioku_index_set_param(eioku_index* ix, const char* name, long long value) {
   EIOKU_REQUIRE(ix && name, "bad argument");
   if (!strcmp(name, "scan_mode")) {
-    EIOKU_REQUIRE(value >= 0 && value <= 2, "scan_mode is 0 (off), 1 (three-term) or 2 (one-term + exact re-rank)");
+    EIOKU_REQUIRE(value == 0 || value == 1, "scan_mode is 0 (register-tile kernels only) or 1 (scan path for wide searches)");
     ix->scan_mode = (int)value;
   } else if (!strcmp(name, "scan_cap")) {
     EIOKU_REQUIRE(value >= 16 && value <= 16384, "scan_cap must be in [16, 16384]");
@@ -1518,9 +1556,9 @@ int eioku_index_set_param(eioku_index* ix, const char* name, long long value) {
   } else if (!strcmp(name, "scan_sample")) {
     EIOKU_REQUIRE(value >= 0, "scan_sample must be >= 0");
     ix->scan_sample = value;
-  } else if (!strcmp(name, "scan_waves")) {
-    EIOKU_REQUIRE(value == 0 || value == 4 || value == 8, "scan_waves must be 0, 4 or 8");
-    ix->scan_waves = (int)value;
+  } else if (!strcmp(name, "scan_rt")) {
+    EIOKU_REQUIRE(value == 1 || value == 2, "scan_rt must be 1 or 2");
+    ix->scan_rt = (int)value;
   } else {
     set_error("unknown index parameter '%s'", name);
     return EIOKU_EINVAL;

@@ -193,7 +193,7 @@ int eioku_yolo_postprocess(const float* const* box_dev, const float* const* cls_
  * search() returns SQUARED L2 distances ascending and int64 ids (-1 / FLT_MAX when fewer than k
  * vectors exist), ties broken by the smaller id.  d in {64,128,256,384,512}, k <= 32.
  * HBM layout: the fp32 rows [N][d] (+ fp32 norms) and, built lazily by the first search with nq > 64 over
- * >= scan_min_rows rows, a bf16 copy in MFMA-fragment order (hi plane, optionally lo plane: 2 d bytes per row each).
+ * >= scan_min_rows rows, a bf16 copy of the rows in MFMA-fragment order (2 d bytes per row).
  */
 typedef struct eioku_index eioku_index_t;
 int eioku_index_flat_create(int d, eioku_index_t** out);
@@ -211,10 +211,11 @@ int eioku_index_search(eioku_index_t* ix, const float* q, int nq, int k, float* 
  * the k <= 32 of one search: successive rounds on the exact-fp32 kernels see bit-identical distances). */
 int eioku_index_search_after(eioku_index_t* ix, const float* q, int nq, int k, const float* after_D,
                              const int64_t* after_I, float* D, int64_t* I, int mem, void* stream);
-/* Tuning / test knobs of the wide-search ("scan") path, see csrc/knn.hip: "scan_mode" 0 off, 1 three-term split-bf16
- * products, 2 (default) one-term bf16 filter + exact fp32 re-rank of the candidates; "scan_cap" candidate slots per
- * query (a list that overflows falls back to the register-tile kernels); "scan_min_rows"; "scan_sample" rows of the
- * bounding sample (0 = automatic); "scan_waves" 0 (automatic), 4 or 8 waves per workgroup. */
+/* Tuning / test knobs of the wide-search ("scan") path, see csrc/knn.hip: "scan_mode" 0 = register-tile kernels only,
+ * 1 (default) = searches with nq > 64 over >= "scan_min_rows" rows keep row tiles stationary, filter with one bf16
+ * product term and re-rank the candidates in fp32; "scan_cap" candidate slots per query (a list that overflows falls
+ * back to the register-tile kernels); "scan_sample" rows of the bounding sample (0 = automatic); "scan_rt" 1 or 2
+ * row tiles per wave (12 / 8 waves per workgroup). */
 int eioku_index_set_param(eioku_index_t* ix, const char* name, long long value);
 /* C1 helper: merge nlists per-shard results [nlists][nq][k] (ids already global) -> [nq][k].
  * Device pointers.  Used after the RCCL all-gather of per-rank (D, I). */

