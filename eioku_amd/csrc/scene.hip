@@ -12,6 +12,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 using namespace eioku;
 
@@ -70,63 +71,79 @@ __device__ __forceinline__ void flush_sums(unsigned (&acc)[G][C], unsigned (*s_r
 // ---------------------------------------------------------------------------------------
 // K1: luma SAD.  Contiguous planes: thread owns U x 16 B of the plane.
 // ---------------------------------------------------------------------------------------
+// Per-frame sums of one run of frames: every wave reduces its lanes after each frame and adds the result to the
+// workgroup's LDS accumulators (one LDS atomic per wave, frame and channel); the workgroup flushes them to global
+// 64-bit atomics once, at the end of its run.  The frame loop is a plain rolled loop with NO branch in its body (frames
+// past the run re-read the run's last frame and add nothing): behind a branch the compiler cannot count the prefetch
+// in vmcnt and waits for ALL loads before it touches the current frame; unrolled, it hoists eight frames of loads and
+// spills.
+constexpr int kMaxSeg = 64;
+
+template <int C>
+__device__ __forceinline__ void flush_run(const unsigned* s_acc, int t_begin, int t_end, unsigned long long* out) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < (t_end - t_begin) * C; i += kBlock) {
+    const unsigned v = s_acc[i];
+    if (v) atomicAdd(&out[(size_t)t_begin * C + i], (unsigned long long)v);
+  }
+}
+
 template <int U>
 __global__ __launch_bounds__(kBlock) void k_sad_luma(const uint8_t* __restrict__ frames,
                                                      size_t frame_stride, int n,
                                                      unsigned long long plane_bytes,
                                                      const uint8_t* __restrict__ prev, int seg,
                                                      unsigned long long* __restrict__ sad) {
-  __shared__ unsigned s_red[kBlock / 64][kG];
-  const int tid = threadIdx.x;
+  __shared__ unsigned s_acc[kMaxSeg];
+  const int tid = threadIdx.x, lane = tid & 63;
   const unsigned long long nvec = plane_bytes >> 4;  // the <16-byte tail goes to k_sad_luma_strided
   const int t_begin = blockIdx.y * seg;
   const int t_end = min(n, t_begin + seg);
+  if (tid < kMaxSeg) s_acc[tid] = 0;
+  __syncthreads();
 
+  // Lanes past the end of the plane read vector 0 (a valid address) and are masked to zero
   unsigned long long vidx[U];
-  bool live[U];
+  unsigned mask[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     vidx[u] = ((unsigned long long)blockIdx.x * U + u) * kBlock + tid;
-    live[u] = vidx[u] < nvec;
+    mask[u] = vidx[u] < nvec ? 0xFFFFFFFFu : 0u;
+    if (!mask[u]) vidx[u] = 0;
   }
 
-  uint4 p[U];
+  uint4 p[U], cur[U];
   const uint8_t* pf = t_begin > 0 ? frames + (size_t)(t_begin - 1) * frame_stride : prev;
-  bool have_prev = pf != nullptr;
+  unsigned use = pf != nullptr ? 0xFFFFFFFFu : 0u;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     p[u] = make_uint4(0, 0, 0, 0);
-    if (have_prev && live[u]) p[u] = reinterpret_cast<const uint4*>(pf)[vidx[u]];
+    if (pf) p[u] = reinterpret_cast<const uint4*>(pf)[vidx[u]];
+    cur[u] = reinterpret_cast<const uint4*>(frames + (size_t)t_begin * frame_stride)[vidx[u]];
   }
-
-  for (int t0 = t_begin; t0 < t_end; t0 += kG) {
-    unsigned acc[kG][1];
+#pragma unroll 1
+  for (int t = t_begin; t < t_end; ++t) {
+    uint4 nxt[U];
+    const int tn = t + 1 < t_end ? t + 1 : t;
 #pragma unroll
-    for (int k = 0; k < kG; ++k) acc[k][0] = 0;
+    for (int u = 0; u < U; ++u) nxt[u] = reinterpret_cast<const uint4*>(frames + (size_t)tn * frame_stride)[vidx[u]];
+    unsigned a = 0;
 #pragma unroll
-    for (int k = 0; k < kG; ++k) {
-      const int t = t0 + k;
-      if (t < t_end) {
-        const uint8_t* f = frames + (size_t)t * frame_stride;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          uint4 c = make_uint4(0, 0, 0, 0);
-          if (live[u]) c = reinterpret_cast<const uint4*>(f)[vidx[u]];
-          if (have_prev) {
-            unsigned a = acc[k][0];
-            a = __builtin_amdgcn_sad_u8(c.x, p[u].x, a);
-            a = __builtin_amdgcn_sad_u8(c.y, p[u].y, a);
-            a = __builtin_amdgcn_sad_u8(c.z, p[u].z, a);
-            a = __builtin_amdgcn_sad_u8(c.w, p[u].w, a);
-            acc[k][0] = a;
-          }
-          p[u] = c;
-        }
-        have_prev = true;
-      }
+    for (int u = 0; u < U; ++u) {
+      unsigned d = 0;
+      d = __builtin_amdgcn_sad_u8(cur[u].x, p[u].x, d);
+      d = __builtin_amdgcn_sad_u8(cur[u].y, p[u].y, d);
+      d = __builtin_amdgcn_sad_u8(cur[u].z, p[u].z, d);
+      d = __builtin_amdgcn_sad_u8(cur[u].w, p[u].w, d);
+      a += d & mask[u];
+      p[u] = cur[u];
+      cur[u] = nxt[u];
     }
-    flush_sums<kG, 1>(acc, s_red, t0, t_end, sad);
+    a = wave_reduce_add(a & use);
+    if (lane == 0 && a) atomicAdd(&s_acc[t - t_begin], a);
+    use = 0xFFFFFFFFu;
   }
+  flush_run<1>(s_acc, t_begin, t_end, sad);
 }
 
 // Generic (row-strided or unaligned) planes: byte loads, 16 pixels per thread.
@@ -234,7 +251,8 @@ __device__ __forceinline__ Quad3 load_quad(const uint8_t* __restrict__ f, unsign
   return r;
 }
 
-// thread owns Q pixel quads per frame; a workgroup covers Q*256 quads = Q*1024 pixels.
+// thread owns Q pixel quads per frame; a workgroup covers Q*256 quads = Q*1024 pixels; the next frame is in flight
+// (registers) while one is converted.  Loop structure and per-frame reduction: see k_sad_luma.
 template <int Q, bool ALIGNED>
 __global__ __launch_bounds__(kBlock, 4) void k_hsv_sums(const uint8_t* __restrict__ frames,
                                                      size_t frame_stride, int n,
@@ -243,10 +261,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_hsv_sums(const uint8_t* __restric
                                                      unsigned long long* __restrict__ sums) {
   __shared__ int s_sdiv[256];
   __shared__ int s_hdiv[256];
-  __shared__ unsigned s_red[kBlock / 64][kG * 3];
-  const int tid = threadIdx.x;
+  __shared__ unsigned s_acc[kMaxSeg * 3];
+  const int tid = threadIdx.x, lane = tid & 63;
   s_sdiv[tid] = c_sdiv[tid];
   s_hdiv[tid] = c_hdiv[tid];
+  if (tid < kMaxSeg * 3) s_acc[tid] = 0;
   __syncthreads();
 
   const unsigned long long nquads = npix >> 2;  // the <4-pixel tail goes to k_hsv_sums_tail
@@ -266,64 +285,57 @@ __global__ __launch_bounds__(kBlock, 4) void k_hsv_sums(const uint8_t* __restric
 
   unsigned pH[Q], pS[Q], pV[Q];
   const uint8_t* pf = t_begin > 0 ? frames + (size_t)(t_begin - 1) * frame_stride : prev;
-  bool have_prev = pf != nullptr;
+  unsigned use = pf != nullptr ? 0xFFFFFFFFu : 0u;
+  Quad3 cur[Q];
 #pragma unroll
   for (int u = 0; u < Q; ++u) {
     pH[u] = pS[u] = pV[u] = 0;
-    if (have_prev) {
+    if (pf) {
       Quad3 d = load_quad<ALIGNED>(pf, q[u]);
       hsv_quad(d.d0, d.d1, d.d2, s_sdiv, s_hdiv, pH[u], pS[u], pV[u]);
       pH[u] &= mask[u];
       pS[u] &= mask[u];
       pV[u] &= mask[u];
     }
+    cur[u] = load_quad<ALIGNED>(frames + (size_t)t_begin * frame_stride, q[u]);
   }
-
-  // software pipeline: frame t+1 is in flight while frame t is converted
-  Quad3 cur[Q];
+#pragma unroll 1
+  for (int t = t_begin; t < t_end; ++t) {
+    Quad3 nxt[Q];
+    {
+      const int tn = t + 1 < t_end ? t + 1 : t;
+      const uint8_t* f = frames + (size_t)tn * frame_stride;
 #pragma unroll
-  for (int u = 0; u < Q; ++u) cur[u] = load_quad<ALIGNED>(frames + (size_t)t_begin * frame_stride, q[u]);
-
-  for (int t0 = t_begin; t0 < t_end; t0 += kG) {
-    unsigned acc[kG][3];
-#pragma unroll
-    for (int k = 0; k < kG; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0;
-#pragma unroll
-    for (int k = 0; k < kG; ++k) {
-      const int t = t0 + k;
-      if (t < t_end) {
-        Quad3 nxt[Q];
-        {
-          // unconditional (the last frame is re-read once): behind a branch the compiler cannot count the load
-          // and waits for it with vmcnt(0) BEFORE converting the current frame
-          const int tn = t + 1 < t_end ? t + 1 : t_end - 1;
-          const uint8_t* f = frames + (size_t)tn * frame_stride;
-#pragma unroll
-          for (int u = 0; u < Q; ++u) nxt[u] = load_quad<ALIGNED>(f, q[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < Q; ++u) {
-          unsigned H, S, V;
-          hsv_quad(cur[u].d0, cur[u].d1, cur[u].d2, s_sdiv, s_hdiv, H, S, V);
-          H &= mask[u];
-          S &= mask[u];
-          V &= mask[u];
-          if (have_prev) {
-            acc[k][0] = __builtin_amdgcn_sad_u8(H, pH[u], acc[k][0]);
-            acc[k][1] = __builtin_amdgcn_sad_u8(S, pS[u], acc[k][1]);
-            acc[k][2] = __builtin_amdgcn_sad_u8(V, pV[u], acc[k][2]);
-          }
-          pH[u] = H;
-          pS[u] = S;
-          pV[u] = V;
-        }
-        have_prev = true;
-#pragma unroll
-        for (int u = 0; u < Q; ++u) cur[u] = nxt[u];
-      }
+      for (int u = 0; u < Q; ++u) nxt[u] = load_quad<ALIGNED>(f, q[u]);
     }
-    flush_sums<kG, 3>(acc, s_red, t0, t_end, sums);
+    unsigned aH = 0, aS = 0, aV = 0;
+#pragma unroll
+    for (int u = 0; u < Q; ++u) {
+      unsigned H, S, V;
+      hsv_quad(cur[u].d0, cur[u].d1, cur[u].d2, s_sdiv, s_hdiv, H, S, V);
+      H &= mask[u];
+      S &= mask[u];
+      V &= mask[u];
+      aH = __builtin_amdgcn_sad_u8(H, pH[u], aH);
+      aS = __builtin_amdgcn_sad_u8(S, pS[u], aS);
+      aV = __builtin_amdgcn_sad_u8(V, pV[u], aV);
+      pH[u] = H;
+      pS[u] = S;
+      pV[u] = V;
+      cur[u] = nxt[u];
+    }
+    aH = wave_reduce_add(aH & use);
+    aS = wave_reduce_add(aS & use);
+    aV = wave_reduce_add(aV & use);
+    if (lane == 0) {
+      unsigned* a = s_acc + (t - t_begin) * 3;
+      if (aH) atomicAdd(a, aH);
+      if (aS) atomicAdd(a + 1, aS);
+      if (aV) atomicAdd(a + 2, aV);
+    }
+    use = 0xFFFFFFFFu;
   }
+  flush_run<3>(s_acc, t_begin, t_end, sums);
 }
 
 // pixels [pix_begin, npix) (< 4 of them): one thread per pixel walks all frames.
@@ -383,6 +395,7 @@ __global__ __launch_bounds__(kBlock) void k_bgr2hsv(const uint8_t* __restrict__ 
 int pick_seg(int n, unsigned long long blocks_x) {
   const unsigned long long want = (unsigned long long)num_cus() * 8;
   int seg = ((n + kG - 1) / kG) * kG;  // one run
+  if (seg > kMaxSeg) seg = kMaxSeg;     // the run's sums live in LDS
   while (seg > kG && blocks_x * (unsigned long long)((n + seg - 1) / seg) < want) {
     seg = ((seg / 2 + kG - 1) / kG) * kG;
   }
@@ -429,7 +442,9 @@ int eioku_scene_sad_luma(const uint8_t* y_frames, int n, int h, int w, size_t ro
   const bool contiguous = row_stride == (size_t)w;
   const bool aligned = (((uintptr_t)d_frames | frame_stride | (d_prev ? (uintptr_t)d_prev : 0)) & 15) == 0;
   if (contiguous && aligned) {
-    constexpr int U = 2;
+    // 4 x 16 B per thread, loads issued frame by frame (r02 sweep: 4.6-4.7 TB/s at 64 x 1080p = 28 us for 133 MB, the
+    // copy-kernel rate of this chip minus launch ramp; deeper explicit prefetch was SLOWER: 3.8-4.5 TB/s)
+    constexpr int U = 4;
     unsigned long long plane = (unsigned long long)h * w;
     unsigned long long nvec = plane >> 4;
     unsigned long long bx = (nvec + (unsigned long long)kBlock * U - 1) / ((unsigned long long)kBlock * U);
@@ -438,8 +453,7 @@ int eioku_scene_sad_luma(const uint8_t* y_frames, int n, int h, int w, size_t ro
     dim3 grid((unsigned)bx, (unsigned)((n + seg - 1) / seg));
     if (nvec) {
       prof_start(EIOKU_PROF_SCENE_SAD, stream);
-      hipLaunchKernelGGL(k_sad_luma<U>, grid, dim3(kBlock), 0, stream, d_frames, frame_stride, n,
-                         plane, d_prev, seg, d_out);
+      hipLaunchKernelGGL((k_sad_luma<U>), grid, dim3(kBlock), 0, stream, d_frames, frame_stride, n, plane, d_prev, seg, d_out);
       prof_stop(EIOKU_PROF_SCENE_SAD, stream);
     }
     if (plane & 15)  // ragged tail (< 16 bytes)
@@ -495,7 +509,10 @@ int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t 
   }
   EIOKU_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint64_t) * 3 * n, stream));
 
-  constexpr int Q = 2;
+  // Q = 4 quads per thread, one frame ahead, 4 waves per SIMD: the r02 sweep (profiles/r02_scene_sweep.txt) moved K2 by
+  // < 4 % over quads 1..4 x frames in flight 1..4 x 4..16 workgroups per CU - it is bound by its ~30 integer VALU
+  // operations per pixel (the vector pipes are ~76 % busy), not by bytes in flight
+  constexpr int Q = 4;
   const unsigned long long npix = (unsigned long long)h * w;
   unsigned long long nquads = npix >> 2;
   unsigned long long bx = (nquads + (unsigned long long)kBlock * Q - 1) / ((unsigned long long)kBlock * Q);
@@ -505,13 +522,12 @@ int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t 
   const bool aligned = (((uintptr_t)d_frames | frame_stride | (d_prev ? (uintptr_t)d_prev : 0)) & 3) == 0;
   if (nquads) {
     prof_start(EIOKU_PROF_SCENE_HSV, stream);
-    if (aligned) {
-      hipLaunchKernelGGL((k_hsv_sums<Q, true>), grid, dim3(kBlock), 0, stream, d_frames,
-                         frame_stride, n, npix, d_prev, seg, d_out);
-    } else {
-      hipLaunchKernelGGL((k_hsv_sums<Q, false>), grid, dim3(kBlock), 0, stream, d_frames,
-                         frame_stride, n, npix, d_prev, seg, d_out);
-    }
+    if (aligned)
+      hipLaunchKernelGGL((k_hsv_sums<Q, true>), grid, dim3(kBlock), 0, stream, d_frames, frame_stride, n, npix, d_prev,
+                         seg, d_out);
+    else
+      hipLaunchKernelGGL((k_hsv_sums<Q, false>), grid, dim3(kBlock), 0, stream, d_frames, frame_stride, n, npix, d_prev,
+                         seg, d_out);
     prof_stop(EIOKU_PROF_SCENE_HSV, stream);
   }
   if (npix & 3)
