@@ -337,6 +337,30 @@ int eioku_kmeans_update(const float* x_dev, long long n, int d, const long long*
   return EIOKU_OK;
 }
 
+// The two halves of eioku_kmeans_update, for a build sharded over GPUs: every rank ADDS its rows into sums / counts
+// (caller-zeroed int64 [k][d] in 2^-32 fixed point / int32 [k]), the ranks all-reduce the integers (exact and order
+// independent: the sharded centroids are the single-GPU ones bit for bit) and every rank finalises.
+int eioku_kmeans_accumulate(const float* x_dev, long long n, int d, const long long* assign_dev, int k,
+                            long long* sums_dev, int* counts_dev, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(x_dev && assign_dev && sums_dev && counts_dev && n >= 0 && d > 0 && k > 0, "bad argument");
+  if (n == 0) return EIOKU_OK;
+  hipLaunchKernelGGL(k_kmeans_accumulate, dim3(grid_cap(n * 64, 256)), dim3(256), 0, (hipStream_t)stream_, x_dev, n, d,
+                     assign_dev, sums_dev, counts_dev);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+int eioku_kmeans_finalize(const long long* sums_dev, const int* counts_dev, int k, int d, float* centroids_dev,
+                          void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(sums_dev && counts_dev && centroids_dev && d > 0 && k > 0, "bad argument");
+  hipLaunchKernelGGL(k_kmeans_finalize, dim3((unsigned)(((long long)k * d + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                     sums_dev, counts_dev, k, d, centroids_dev);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
 // Nearest PQ sub-centroid per (vector, sub-quantiser) of x (or of x - coarse[list] when coarse != NULL).
 // codes_out [n][m] uint8 and/or resid_out [n][d] may be NULL.  d = m * dsub, dsub in {4, 8, 16}.
 int eioku_pq_assign(const float* x_dev, long long n, int d, int m, const float* coarse_dev, const long long* list_dev,

@@ -10,6 +10,11 @@ PQ assignment / encoding, counting-sort into lists, ADC scan with LUT in LDS, to
 Deviations from FAISS defaults, all deterministic: k-means initialises from
 ``default_rng(seed).permutation(n)[:k]``, an empty cluster keeps its previous centroid (FAISS splits
 the largest), 25 iterations, at most 256 training points per centroid.
+
+Multi-GPU build (BASELINE cfg5: 100M x 384 over 8 GPUs): ``train(x, group=...)`` trains the
+quantisers on the union of every rank's rows with one integer all-reduce per k-means iteration; ``add`` /
+``search`` stay local to the rank's row shard, and ``search.ShardedFlatL2(local=this index, id_base=...)`` merges
+the per-rank results with the single all-gather of the flat index.
 """
 
 from __future__ import annotations
@@ -29,19 +34,101 @@ def _sample(n: int, want: int, seed: int) -> np.ndarray:
     return np.sort(perm[:want]) if want < n else np.arange(n)
 
 
+class HipTrainOps:
+    """The data-parallel steps of training on this rank's rows, on the HIP kernels.  (A seam: the world-size-2 gloo
+    test drives :meth:`IndexIVFPQ.train` on CPU ranks with a numpy stand-in of the same integer arithmetic.)"""
+
+    def __init__(self, device):
+        self._lib = _lib.load()
+        self.device = device
+
+    def to_device(self, a):
+        import torch
+
+        return torch.as_tensor(a, dtype=torch.float32).to(self.device).contiguous()
+
+    def take(self, x, idx):
+        import torch
+
+        return x[torch.from_numpy(np.asarray(idx)).to(x.device)].contiguous()
+
+    def assign(self, x, cent):
+        """nearest centroid of every row (int64): K9 with k = 1"""
+        flat = IndexFlatL2(int(cent.shape[1]))
+        flat.attach(cent)
+        _, a = flat.search(x, 1)
+        a = a.reshape(-1).contiguous()
+        flat.close()
+        return a
+
+    def accumulate(self, x, assign, k):
+        """int64 (k, d + 1): per-centroid sums of the assigned rows in 2^-32 fixed point, and the count in column d"""
+        import torch
+
+        n, d = (int(v) for v in x.shape)
+        sums = torch.zeros((k, d), dtype=torch.int64, device=x.device)
+        counts = torch.zeros((k,), dtype=torch.int32, device=x.device)
+        _lib.check(self._lib.eioku_kmeans_accumulate(ptr(x), n, d, ptr(assign), k, ptr(sums), ptr(counts), current_stream(x)),
+                   "eioku_kmeans_accumulate")
+        return torch.cat([sums, counts.to(torch.int64)[:, None]], 1).contiguous()
+
+    def finalize(self, packed, cent):
+        """centroids <- sums / counts (a centroid without rows keeps its value); in place"""
+        import torch
+
+        k, d = (int(v) for v in cent.shape)
+        sums = packed[:, :d].contiguous()
+        counts = packed[:, d].to(torch.int32).contiguous()
+        _lib.check(self._lib.eioku_kmeans_finalize(ptr(sums), ptr(counts), k, d, ptr(cent), current_stream(cent)),
+                   "eioku_kmeans_finalize")
+        return cent
+
+    def residuals(self, x, coarse, lst, m):
+        import torch
+
+        resid = torch.empty_like(x)
+        dummy = torch.zeros((m, 256, x.shape[1] // m), dtype=torch.float32, device=x.device)
+        _lib.check(self._lib.eioku_pq_assign(ptr(x), x.shape[0], x.shape[1], m, ptr(coarse), ptr(lst), ptr(dummy), None, ptr(resid),
+                                             current_stream(x)), "eioku_pq_assign(residual)")
+        return resid
+
+    def pq_codes(self, resid, pq):
+        import torch
+
+        n, d = (int(v) for v in resid.shape)
+        codes = torch.empty((n, pq.shape[0]), dtype=torch.uint8, device=resid.device)
+        _lib.check(self._lib.eioku_pq_assign(ptr(resid), n, d, int(pq.shape[0]), None, None, ptr(pq), ptr(codes), None,
+                                             current_stream(resid)), "eioku_pq_assign(train)")
+        return codes
+
+    def column(self, x, lo, hi):
+        return x[:, lo:hi].contiguous()
+
+    def codes_column(self, codes, j):
+        import torch
+
+        return codes[:, j].to(torch.int64).contiguous()
+
+
 class IndexIVFPQ:
-    def __init__(self, d: int, nlist: int, m: int, nbits: int = 8, device=None, seed: int = 1234):
+    def __init__(self, d: int, nlist: int, m: int, nbits: int = 8, device=None, seed: int = 1234, train_ops=None):
         import torch
 
         if nbits != 8:
             raise ValueError("only 8-bit PQ codes are supported")
         if d % m or d // m not in (4, 8, 16):
             raise ValueError("d/m must be 4, 8 or 16")
-        self._lib = _lib.load()
-        _lib.init()
         self.d, self.nlist, self.m, self.dsub, self.seed = d, nlist, m, d // m, seed
         self.nprobe = 1
-        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        if train_ops is None:
+            self._lib = _lib.load()
+            _lib.init()
+            self.device = device or torch.device("cuda", torch.cuda.current_device())
+            train_ops = HipTrainOps(self.device)
+        else:
+            self._lib = None
+            self.device = device
+        self._ops = train_ops
         self.is_trained = False
         self.coarse = None          # (nlist, d) float32 cuda
         self.pq = None              # (m, 256, dsub) float32 cuda
@@ -49,59 +136,70 @@ class IndexIVFPQ:
         self._pending = []          # (list int64, codes uint8, id_base) per add() batch
         self.ntotal = 0
         self._packed = None
+        self.allreduce_calls = 0
 
     # ---- training ------------------------------------------------------------------------------
-    def _kmeans(self, x, k: int, seed: int):
-        """Lloyd iterations on a CUDA (n,d) tensor -> (k,d) centroids; assignment on the MFMA flat kernel."""
-        import torch
+    def _allreduce(self, packed, group):
+        """Sum the integer (sums | counts) table over the ranks of ``group`` (RCCL on GPUs): exact and order
+        independent, so every rank - and a single-GPU run over the same rows - finalises the same centroids."""
+        if group is None:
+            return packed
+        import torch.distributed as dist
 
-        n, d = x.shape
-        init = np.random.default_rng(seed).permutation(n)[:k]
-        cent = x[torch.from_numpy(np.sort(init)).to(x.device)].clone().contiguous()
-        flat = IndexFlatL2(d)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        self.allreduce_calls += 1
+        return packed
+
+    def _bcast(self, t, group):
+        if group is not None:
+            import torch.distributed as dist
+
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if hasattr(dist, "get_global_rank") else 0, group=group)
+        return t
+
+    def _kmeans(self, x, k: int, seed: int, group=None):
+        """Lloyd iterations on this rank's (n,d) rows -> (k,d) centroids shared by every rank of ``group``:
+        assignment on the MFMA flat kernel, one all-reduce of k x (d + 1) int64 per iteration."""
+        ops = self._ops
+        n = int(x.shape[0])
+        init = np.sort(np.random.default_rng(seed).permutation(n)[:k])
+        cent = self._bcast(ops.take(x, init).clone(), group)  # rank 0's picks seed every rank
         for _ in range(NITER):
-            flat.attach(cent)
-            _, assign = flat.search(x, 1)
-            assign = assign.reshape(-1).contiguous()
-            _lib.check(self._lib.eioku_kmeans_update(ptr(x), n, d, ptr(assign), k, ptr(cent), None, current_stream(x)),
-                       "eioku_kmeans_update")
-        flat.close()
+            packed = self._allreduce(ops.accumulate(x, ops.assign(x, cent), k), group)
+            cent = ops.finalize(packed, cent)
         return cent
 
-    def train(self, x) -> None:
-        """``x``: float32 (n,d) numpy array or CUDA tensor."""
+    def train(self, x, group=None) -> None:
+        """``x``: float32 (n,d) rows of THIS rank (numpy array or CUDA tensor).  ``group``: a ``torch.distributed``
+        group (RCCL on GPUs) whose ranks each hold a shard of the training rows: the quantisers are trained on the
+        union - per k-means iteration ONE all-reduce of ``nlist x (d + 1)`` (coarse) / ``m x 256 x (dsub + 1)`` (PQ)
+        integers - and come out identical on every rank."""
+        ops = self._ops
+        x = ops.to_device(x)
+        n = int(x.shape[0])
+        if n < max(self.nlist, 256):
+            raise ValueError(f"need at least max(nlist={self.nlist}, 256) training vectors on every rank (the k-means seeds), got {n}")
+        xs = ops.take(x, _sample(n, MAX_POINTS_PER_CENTROID * self.nlist, self.seed))
+        self.coarse = self._kmeans(xs, self.nlist, self.seed + 1, group)
+        # PQ on residuals of (at most 65536 per rank) training vectors
+        xp = ops.take(x, _sample(n, MAX_POINTS_PER_CENTROID * 256, self.seed + 2))
+        lst = ops.assign(xp, self.coarse)
+        resid = ops.residuals(xp, self.coarse, lst, self.m)
+        npq = int(resid.shape[0])
+        init = np.sort(np.random.default_rng(self.seed + 3).permutation(npq)[:256])
+        pq = self._bcast(ops.take(resid, init).reshape(256, self.m, self.dsub).permute(1, 0, 2).contiguous(), group)
         import torch
 
-        x = torch.as_tensor(x, dtype=torch.float32).to(self.device).contiguous()
-        n = x.shape[0]
-        if n < self.nlist:
-            raise ValueError(f"need at least nlist={self.nlist} training vectors, got {n}")
-        xs = x[torch.from_numpy(_sample(n, MAX_POINTS_PER_CENTROID * self.nlist, self.seed)).to(self.device)].contiguous()
-        self.coarse = self._kmeans(xs, self.nlist, self.seed + 1)
-        self._quantizer = IndexFlatL2(self.d)
-        self._quantizer.attach(self.coarse)
-        # PQ on residuals of (at most 65536) training vectors
-        xp = x[torch.from_numpy(_sample(n, MAX_POINTS_PER_CENTROID * 256, self.seed + 2)).to(self.device)].contiguous()
-        _, lst = self._quantizer.search(xp, 1)
-        lst = lst.reshape(-1).contiguous()
-        resid = torch.empty_like(xp)
-        dummy_pq = torch.zeros((self.m, 256, self.dsub), dtype=torch.float32, device=self.device)
-        _lib.check(self._lib.eioku_pq_assign(ptr(xp), xp.shape[0], self.d, self.m, ptr(self.coarse), ptr(lst), ptr(dummy_pq),
-                                             None, ptr(resid), current_stream(xp)), "eioku_pq_assign(residual)")
-        npq = resid.shape[0]
-        init = np.sort(np.random.default_rng(self.seed + 3).permutation(npq)[:256])
-        pq = resid[torch.from_numpy(init).to(self.device)].reshape(256, self.m, self.dsub).permute(1, 0, 2).contiguous()
-        codes = torch.empty((npq, self.m), dtype=torch.uint8, device=self.device)
         for _ in range(NITER):
-            _lib.check(self._lib.eioku_pq_assign(ptr(resid), npq, self.d, self.m, None, None, ptr(pq), ptr(codes), None,
-                                                 current_stream(resid)), "eioku_pq_assign(train)")
-            for j in range(self.m):
-                sub = resid[:, j * self.dsub:(j + 1) * self.dsub].contiguous()
-                a = codes[:, j].to(torch.int64).contiguous()
-                cj = pq[j]
-                _lib.check(self._lib.eioku_kmeans_update(ptr(sub), npq, self.dsub, ptr(a), 256, ptr(cj), None,
-                                                         current_stream(sub)), "eioku_kmeans_update(pq)")
+            codes = ops.pq_codes(resid, pq)
+            packed = torch.stack([ops.accumulate(ops.column(resid, j * self.dsub, (j + 1) * self.dsub),
+                                                 ops.codes_column(codes, j), 256) for j in range(self.m)])
+            packed = self._allreduce(packed.contiguous(), group)  # (m, 256, dsub + 1): one collective for all sub-quantisers
+            pq = torch.stack([ops.finalize(packed[j], pq[j].contiguous()) for j in range(self.m)]).contiguous()
         self.pq = pq
+        if self._lib is not None:
+            self._quantizer = IndexFlatL2(self.d)
+            self._quantizer.attach(self.coarse)
         self.is_trained = True
 
     def set_codebooks(self, coarse, pq) -> None:
@@ -110,6 +208,8 @@ class IndexIVFPQ:
 
         self.coarse = torch.as_tensor(coarse, dtype=torch.float32).to(self.device).contiguous()
         self.pq = torch.as_tensor(pq, dtype=torch.float32).to(self.device).contiguous()
+        if self._quantizer is not None:
+            self._quantizer.close()
         self._quantizer = IndexFlatL2(self.d)
         self._quantizer.attach(self.coarse)
         self.is_trained = True

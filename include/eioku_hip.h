@@ -260,6 +260,13 @@ int eioku_topk_merge_ex(const float* d_lists, const int64_t* i_lists, int nlists
  */
 int eioku_kmeans_update(const float* x_dev, long long n, int d, const long long* assign_dev, int k,
                         float* centroids_dev, int* counts_out_dev, void* stream);
+/* the two halves of eioku_kmeans_update for a build sharded over GPUs: every rank adds its rows
+ * into caller-zeroed integer sums (int64 [k][d], 2^-32 fixed point) and counts (int32 [k]), the host all-reduces them
+ * (RCCL; integers: exact, order independent) and every rank finalises the same centroids. */
+int eioku_kmeans_accumulate(const float* x_dev, long long n, int d, const long long* assign_dev, int k,
+                            long long* sums_dev, int* counts_dev, void* stream);
+int eioku_kmeans_finalize(const long long* sums_dev, const int* counts_dev, int k, int d, float* centroids_dev,
+                          void* stream);
 int eioku_pq_assign(const float* x_dev, long long n, int d, int m, const float* coarse_dev,
                     const long long* list_dev, const float* pq_dev, uint8_t* codes_out_dev,
                     float* resid_out_dev, void* stream);

@@ -170,3 +170,48 @@ def test_nprobe_above_32_matches_the_oracle_scan(gpu):
     Dt, It = oknn.search(x, q, 10)
     recall = np.mean([len(set(I[i]) & set(It[i])) / 10 for i in range(len(q))])
     assert recall > 0.25  # every list probed: only the (coarse, m = 8) PQ quantisation separates it from the exact answer
+
+
+def test_cfg5_geometry_nlist4096_m48_and_sharded_wrapper(gpu):
+    """BASELINE cfg5's geometry on one GPU's worth of a small shard: d 384, nlist 4096, m 48 (8-dim sub-vectors), nprobe 32,
+    trained by the product loop (one integer reduction per k-means iteration; `group=None` here), searched through the
+    same ShardedFlatL2 wrapper the 8-GPU run uses (world 1: no collective).  Clustered unit vectors: recall against the
+    exact index is the quality bar, planted exact copies must come back first."""
+    import torch
+
+    d, nlist, m, n, nq = 384, 4096, 48, 200_000, 256
+    rng = np.random.default_rng(11)
+    centers = rng.standard_normal((2000, d)).astype(np.float32)
+    x = centers[rng.integers(0, 2000, n)] + 0.25 * rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    q = x[rng.integers(0, n, nq)] + 0.02 * rng.standard_normal((nq, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[:16] = x[1000:1016]
+    xd, qd = torch.from_numpy(x).to(gpu), torch.from_numpy(q).to(gpu)
+    ix = ivfpq.IndexIVFPQ(d, nlist, m)
+    ix.train(xd)
+    assert ix.allreduce_calls == 0 and tuple(ix.coarse.shape) == (nlist, d) and tuple(ix.pq.shape) == (m, 256, 8)
+    ix.add(xd[:120_000])
+    ix.add(xd[120_000:])
+    ix.nprobe = 32
+    sh = search.ShardedFlatL2(ix, id_base=0)
+    D, I = sh.search(qd, 10)
+    I = I.cpu().numpy()
+    assert list(I[:16, 0]) == list(range(1000, 1016))
+    flat = search.IndexFlatL2(d)
+    flat.attach(xd)
+    _, It = flat.search(qd, 10)
+    It = It.cpu().numpy()
+    recall = np.mean([len(set(I[i]) & set(It[i])) / 10 for i in range(nq)])
+    r1 = np.mean([It[i, 0] in I[i] for i in range(nq)])
+    assert recall > 0.6 and r1 > 0.9, (recall, r1)
+    # the two halves of the k-means update are the whole update (what the sharded build relies on)
+    from eioku_amd import _lib
+    from eioku_amd._buffers import ptr
+
+    ops = ivfpq.HipTrainOps(gpu)
+    a = ops.assign(xd[:5000].contiguous(), ix.coarse)
+    c1 = ix.coarse.clone()
+    _lib.check(_lib.load().eioku_kmeans_update(ptr(xd[:5000].contiguous()), 5000, d, ptr(a), nlist, ptr(c1), None, None), "kmeans_update")
+    c2 = ops.finalize(ops.accumulate(xd[:5000].contiguous(), a, nlist), ix.coarse.clone())
+    assert torch.equal(c1, c2)
