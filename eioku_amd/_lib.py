@@ -43,6 +43,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "eioku_scene_hsv_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_void_p]),
+    "eioku_scene_sad_luma_bgr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p]),
     "eioku_bgr2hsv": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "eioku_conv2d_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

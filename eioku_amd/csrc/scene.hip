@@ -338,6 +338,77 @@ __global__ __launch_bounds__(kBlock, 4) void k_hsv_sums(const uint8_t* __restric
   flush_run<3>(s_acc, t_begin, t_end, sums);
 }
 
+// K1 on decoded BGR frames (single-pass ingest: the frames the detectors read are the only copy in HBM): the luma
+// is OpenCV's 8-bit COLOR_BGR2YUV_I420 luma, Y = (269484 R + 528482 G + 102760 B + (16 << 20) + (1 << 19)) >> 20
+// (BT.601 studio range, 20-bit fixed point: eioku_amd/frames.py::bgr_to_luma_bt601 on the host), then |Y_t - Y_{t-1}|
+// summed per frame.  Same structure as k_hsv_sums; 3 bytes per pixel, ~8 integer operations per pixel.
+__device__ __forceinline__ unsigned luma_quad(unsigned d0, unsigned d1, unsigned d2) {
+  auto y = [](unsigned b, unsigned g, unsigned r) {
+    return (__umul24(r, 269484u) + __umul24(g, 528482u) + __umul24(b, 102760u) + ((16u << 20) + (1u << 19))) >> 20;
+  };
+  const unsigned y0 = y(d0 & 0xFF, (d0 >> 8) & 0xFF, (d0 >> 16) & 0xFF);
+  const unsigned y1 = y(d0 >> 24, d1 & 0xFF, (d1 >> 8) & 0xFF);
+  const unsigned y2 = y((d1 >> 16) & 0xFF, d1 >> 24, d2 & 0xFF);
+  const unsigned y3 = y((d2 >> 8) & 0xFF, (d2 >> 16) & 0xFF, d2 >> 24);
+  return y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
+}
+
+template <int Q, bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void k_sad_luma_bgr(const uint8_t* __restrict__ frames, size_t frame_stride, int n,
+                                                         unsigned long long npix, const uint8_t* __restrict__ prev, int seg,
+                                                         unsigned long long* __restrict__ sad) {
+  __shared__ unsigned s_acc[kMaxSeg];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < kMaxSeg) s_acc[tid] = 0;
+  __syncthreads();
+  const unsigned long long nquads = npix >> 2;  // a < 4-pixel tail is added by the host wrapper's caller (width % 4 == 0 required)
+  const int t_begin = blockIdx.y * seg;
+  const int t_end = min(n, t_begin + seg);
+  unsigned long long q[Q];
+  unsigned mask[Q];
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    q[u] = ((unsigned long long)blockIdx.x * Q + u) * kBlock + tid;
+    mask[u] = q[u] < nquads ? 0xFFFFFFFFu : 0u;
+    if (!mask[u]) q[u] = 0;
+  }
+  unsigned pY[Q];
+  const uint8_t* pf = t_begin > 0 ? frames + (size_t)(t_begin - 1) * frame_stride : prev;
+  unsigned use = pf != nullptr ? 0xFFFFFFFFu : 0u;
+  Quad3 cur[Q];
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    pY[u] = 0;
+    if (pf) {
+      const Quad3 d = load_quad<ALIGNED>(pf, q[u]);
+      pY[u] = luma_quad(d.d0, d.d1, d.d2) & mask[u];
+    }
+    cur[u] = load_quad<ALIGNED>(frames + (size_t)t_begin * frame_stride, q[u]);
+  }
+#pragma unroll 1
+  for (int t = t_begin; t < t_end; ++t) {
+    Quad3 nxt[Q];
+    {
+      const int tn = t + 1 < t_end ? t + 1 : t;
+      const uint8_t* f = frames + (size_t)tn * frame_stride;
+#pragma unroll
+      for (int u = 0; u < Q; ++u) nxt[u] = load_quad<ALIGNED>(f, q[u]);
+    }
+    unsigned a = 0;
+#pragma unroll
+    for (int u = 0; u < Q; ++u) {
+      const unsigned Y = luma_quad(cur[u].d0, cur[u].d1, cur[u].d2) & mask[u];
+      a = __builtin_amdgcn_sad_u8(Y, pY[u], a);
+      pY[u] = Y;
+      cur[u] = nxt[u];
+    }
+    a = wave_reduce_add(a & use);
+    if (lane == 0 && a) atomicAdd(&s_acc[t - t_begin], a);
+    use = 0xFFFFFFFFu;
+  }
+  flush_run<1>(s_acc, t_begin, t_end, sad);
+}
+
 // pixels [pix_begin, npix) (< 4 of them): one thread per pixel walks all frames.
 __global__ void k_hsv_sums_tail(const uint8_t* __restrict__ frames, size_t frame_stride, int n,
                                 unsigned long long pix_begin, unsigned long long npix,
@@ -536,6 +607,56 @@ int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t 
   EIOKU_LAUNCH_CHECK();
   if (mem == EIOKU_MEM_HOST) {
     EIOKU_HIP_CHECK(hipMemcpyAsync(sums_out, d_out, sizeof(uint64_t) * 3 * n, hipMemcpyDeviceToHost, stream));
+    EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return EIOKU_OK;
+}
+
+int eioku_scene_sad_luma_bgr(const uint8_t* bgr_frames, int n, int h, int w, size_t frame_stride, const uint8_t* prev,
+                             uint64_t* sad_out, int mem, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(n >= 0 && h > 0 && w > 0, "bad shape n=%d h=%d w=%d", n, h, w);
+  EIOKU_REQUIRE(mem == EIOKU_MEM_HOST || mem == EIOKU_MEM_DEVICE, "bad mem flag %d", mem);
+  EIOKU_REQUIRE(((unsigned long long)h * w) % 4 == 0, "h*w = %llu pixels: must be a multiple of 4", (unsigned long long)h * w);
+  const size_t frame_bytes = (size_t)h * w * 3;
+  EIOKU_REQUIRE(frame_stride >= frame_bytes || n <= 1, "frame_stride %zu too small", frame_stride);
+  if (n == 0) return EIOKU_OK;
+  EIOKU_REQUIRE(bgr_frames && sad_out, "NULL buffer");
+  hipStream_t stream = (hipStream_t)stream_;
+  const uint8_t* d_frames = bgr_frames;
+  const uint8_t* d_prev = prev;
+  unsigned long long* d_out = (unsigned long long*)sad_out;
+  if (mem == EIOKU_MEM_HOST) {
+    const size_t total = frame_stride * (size_t)(n - 1) + frame_bytes;
+    uint8_t* din = (uint8_t*)scratch(kSlotIn, total);
+    d_out = (unsigned long long*)scratch(kSlotOut, sizeof(uint64_t) * n);
+    if (!din || !d_out) return EIOKU_ENOMEM;
+    EIOKU_HIP_CHECK(hipMemcpyAsync(din, bgr_frames, total, hipMemcpyHostToDevice, stream));
+    d_frames = din;
+    if (prev) {
+      uint8_t* dp = (uint8_t*)scratch(kSlotPrev, frame_bytes);
+      if (!dp) return EIOKU_ENOMEM;
+      EIOKU_HIP_CHECK(hipMemcpyAsync(dp, prev, frame_bytes, hipMemcpyHostToDevice, stream));
+      d_prev = dp;
+    }
+  }
+  EIOKU_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint64_t) * n, stream));
+  constexpr int Q = 4;
+  const unsigned long long npix = (unsigned long long)h * w;
+  unsigned long long bx = ((npix >> 2) + (unsigned long long)kBlock * Q - 1) / ((unsigned long long)kBlock * Q);
+  if (bx == 0) bx = 1;
+  const int seg = pick_seg(n, bx);
+  dim3 grid((unsigned)bx, (unsigned)((n + seg - 1) / seg));
+  const bool aligned = (((uintptr_t)d_frames | frame_stride | (d_prev ? (uintptr_t)d_prev : 0)) & 3) == 0;
+  prof_start(EIOKU_PROF_SCENE_SAD, stream);
+  if (aligned)
+    hipLaunchKernelGGL((k_sad_luma_bgr<Q, true>), grid, dim3(kBlock), 0, stream, d_frames, frame_stride, n, npix, d_prev, seg, d_out);
+  else
+    hipLaunchKernelGGL((k_sad_luma_bgr<Q, false>), grid, dim3(kBlock), 0, stream, d_frames, frame_stride, n, npix, d_prev, seg, d_out);
+  prof_stop(EIOKU_PROF_SCENE_SAD, stream);
+  EIOKU_LAUNCH_CHECK();
+  if (mem == EIOKU_MEM_HOST) {
+    EIOKU_HIP_CHECK(hipMemcpyAsync(sad_out, d_out, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, stream));
     EIOKU_HIP_CHECK(hipStreamSynchronize(stream));
   }
   return EIOKU_OK;

@@ -138,6 +138,8 @@ class MiniLMEncoder:
         if self.tokenizer is None:
             raise RuntimeError("MiniLMEncoder.encode() needs a tokenizer (vocab.txt of all-MiniLM-L6-v2); "
                                "use encode_ids() with pre-tokenised input otherwise")
+        if hasattr(self.tokenizer, "encode_batch"):  # eioku_amd.semantic.WordPieceTokenizer
+            return self.encode_ids(*self.tokenizer.encode_batch(texts, max_seq_length))
         enc = self.tokenizer(texts, padding=True, truncation=True, max_length=max_seq_length, return_tensors="np")
         return self.encode_ids(enc["input_ids"].astype(np.int32), enc["attention_mask"].astype(np.uint8))
 

@@ -84,10 +84,9 @@ class NpyFrameSource(FrameSource):
         return True
 
     def luma_planes(self, start, count):
-        # raw BGR has no Y plane; BT.601 studio-range integer luma stands in for the decoder's
-        f = self.frames[start:start + count].astype(np.int32)
-        y = ((66 * f[..., 2] + 129 * f[..., 1] + 25 * f[..., 0] + 128) >> 8) + 16
-        return y.astype(np.uint8)
+        # raw BGR has no Y plane: OpenCV's COLOR_BGR2YUV_I420 luma stands in for the decoder's (one definition for every
+        # BGR source, host and device: eioku_scene_sad_luma_bgr computes the same integers)
+        return bgr_to_luma_bt601(np.asarray(self.frames[start:start + count]))
 
 
 class Y4mSource(FrameSource):

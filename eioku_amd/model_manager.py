@@ -235,6 +235,166 @@ class ModelManager:
             logger.error(f"Face detection failed: {e}", exc_info=True)
             raise
 
+    # ---- single pass: one decode, one upload, three stages ------------------------------
+    async def analyze_video(self, video_path: str, configs: dict) -> dict:
+        """Scenes + objects + faces from ONE read of the file.
+
+        The reference opens and decodes the file once per task (``cv2.VideoCapture`` at :237 and :331, an ffmpeg child at
+        :750-755): three decodes of every frame, and the detection loops decode even the frames they skip (``grab()``, :294).
+        Here every frame is read once, goes through pinned host memory into HBM once (chunks of ``batch_size`` frames), and
+        all three stages read that copy: K1 (``eioku_scene_sad_luma_bgr``: the luma OpenCV derives from these BGR frames)
+        on every frame, the two detectors on the frames their own sampling rule picks (``max(1, int(fps * seconds))``,
+        :243 / :337).  ``configs``: ``{"scene_detection": {...}, "object_detection": {...}, "face_detection": {...}}`` -
+        the per-task config dicts the backend would have put into three jobs; a task type that is absent is not run.
+
+        Returns ``{task_type: result}`` with, per task, exactly the dict the separate call returns on a BGR source
+        (``.npy`` clips and cv2 captures whose backend hands back BGR: tests/test_single_pass_gpu.py).  On a capture
+        that can expose the decoder's own Y plane the separate ``detect_scenes`` scores THAT plane (bit-exact with
+        ffmpeg); this entry scores the BGR-derived luma, which differs by the YUV -> BGR -> Y round trip.
+        """
+        import torch
+
+        from . import scene
+        from .detect import PipelinedDetector
+
+        unknown = set(configs) - {"scene_detection", "object_detection", "face_detection"}
+        if unknown:
+            raise NotImplementedError(f"analyze_video covers the hot-path task types only, got {sorted(unknown)}")
+        logger.info(f"Single-pass analysis ({', '.join(sorted(configs))}): {video_path} (device: {self._get_device()})")
+        src = self._open(video_path)
+        fps = src.fps or 30
+        total_frames = int(src.total_frames)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        chunk_n = max(1, self._batch_size)
+        lanes = {}  # task -> detection lane state
+        for task, face, dflt_model, dflt_conf, dflt_sec in (("object_detection", False, "yolov8n.pt", 0.5, 1),
+                                                            ("face_detection", True, "yolov8n-face.pt", 0.7, 3)):
+            if task not in configs:
+                continue
+            cfg = configs[task] or {}
+            detector = self._load_detector(cfg.get("model_name", dflt_model))
+            lanes[task] = {"face": face, "conf": cfg.get("confidence_threshold", dflt_conf),
+                           "interval": max(1, int(fps * cfg.get("frame_interval", dflt_sec))), "names": detector.names,
+                           "pipe": PipelinedDetector(detector, depth=2), "frames": [], "meta": [], "metas": [], "out": []}
+        want_scenes = "scene_detection" in configs
+        scfg = configs.get("scene_detection") or {}
+        content = scfg.get("detector", "ffmpeg") == "content"
+        sums, prev_dev, npx = [], None, 1
+        pinned = [None, None]
+        copied = [None, None]  # events: the chunk's upload has left the pinned buffer
+
+        def emit(lane, meta, dets, counts):
+            for (frame_idx, timestamp_ms), row, cnt in zip(meta, dets, counts):
+                for d in row[: int(cnt)]:
+                    x1, y1, x2, y2 = (np.float32(d[k]) for k in ("x1", "y1", "x2", "y2"))
+                    confidence = float(np.float32(d["conf"]))
+                    if lane["face"] and confidence < lane["conf"]:
+                        continue
+                    det = {"frame_index": frame_idx, "timestamp_ms": timestamp_ms,
+                           "label": "face" if lane["face"] else lane["names"][int(d["cls"])], "confidence": confidence,
+                           "bbox": {"x": float(x1), "y": float(y1), "width": float(np.float32(x2 - x1)),
+                                    "height": float(np.float32(y2 - y1))}}
+                    if lane["face"]:
+                        det["cluster_id"] = None
+                    lane["out"].append(det)
+
+        def drain(lane, keep):
+            while lane["pipe"].in_flight() > keep:
+                emit(lane, lane["metas"].pop(0), *lane["pipe"].result())
+
+        def flush(lane):
+            if not lane["frames"]:
+                return
+            batch = torch.stack(lane["frames"]) if len(lane["frames"]) > 1 else lane["frames"][0][None]
+            lane["pipe"].submit(batch.contiguous(), conf=lane["conf"])
+            lane["metas"].append(list(lane["meta"]))
+            lane["frames"].clear()
+            lane["meta"].clear()
+            drain(lane, lane["pipe"].depth - 1)
+
+        frame_idx, slot = 0, 0
+        try:
+            done = False
+            while not done:
+                host = []
+                while len(host) < chunk_n:
+                    ret, frame = src.read()
+                    if not ret:
+                        done = True
+                        break
+                    host.append(frame)
+                if not host:
+                    break
+                n = len(host)
+                h, w = host[0].shape[:2]
+                npx = h * w
+                if pinned[slot] is None or tuple(pinned[slot].shape[1:]) != (h, w, 3):
+                    pinned = [torch.empty((chunk_n, h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+                    copied = [None, None]
+                if copied[slot] is not None:
+                    copied[slot].synchronize()  # the upload that last used this pinned buffer has finished
+                buf = pinned[slot][:n]
+                for i, f in enumerate(host):
+                    buf[i] = torch.from_numpy(np.ascontiguousarray(f))
+                chunk = buf.to(dev, non_blocking=True)  # the one trip over PCIe
+                ev = torch.cuda.Event()
+                ev.record()
+                copied[slot] = ev
+                slot ^= 1
+                if want_scenes:
+                    if content:
+                        sums.append(scene.hsv_sums(chunk, prev_dev, keep_on_device=True))
+                    elif npx % 4 == 0:
+                        sums.append(scene.luma_sad_bgr(chunk, prev_dev, keep_on_device=True))
+                    else:  # odd pixel counts: luma plane on the device, then K1
+                        c = chunk.to(torch.int64)
+                        y = ((269484 * c[..., 2] + 528482 * c[..., 1] + 102760 * c[..., 0] + (16 << 20) + (1 << 19)) >> 20).to(torch.uint8)
+                        py = None
+                        if prev_dev is not None:
+                            p = prev_dev.to(torch.int64)
+                            py = ((269484 * p[..., 2] + 528482 * p[..., 1] + 102760 * p[..., 0] + (16 << 20) + (1 << 19)) >> 20).to(torch.uint8)
+                        sums.append(scene.luma_sad(y.contiguous(), py.contiguous() if py is not None else None, keep_on_device=True))
+                    prev_dev = chunk[n - 1]
+                for lane in lanes.values():
+                    for i in range(n):
+                        idx = frame_idx + i
+                        if idx % lane["interval"] == 0:
+                            lane["frames"].append(chunk[i])
+                            lane["meta"].append((idx, int((idx / fps) * 1000)))
+                            if len(lane["frames"]) >= self._batch_size:
+                                flush(lane)
+                frame_idx += n
+            for lane in lanes.values():
+                flush(lane)
+                drain(lane, 0)
+        finally:
+            src.release()
+            for lane in lanes.values():
+                lane["pipe"].close()
+        out = {}
+        for task, lane in lanes.items():
+            out[task] = {"detections": lane["out"]}
+        if want_scenes:
+            tb_num, tb_den = src.time_base
+            duration_ms = None if src.duration_s is None else int(float(src.duration_s) * 1000)
+            s_all = torch.cat(sums).cpu().numpy() if sums else np.zeros((0, 3) if content else (0,), np.uint64)
+            if content:
+                scores = scene.content_scores(s_all, npx)
+                cuts = scene.content_cuts(scores, float(scfg.get("content_threshold", 27.0)), int(scfg.get("min_scene_len", 15)),
+                                          scfg.get("filter_mode", "legacy"))
+                ts = [0] + [int(float(scene.pts_time_string(c, tb_num, tb_den)) * 1000) for c in cuts]
+                end = duration_ms if duration_ms is not None else (ts[-1] + 1000)
+                out["scene_detection"] = {"scenes": [{"scene_index": i, "start_ms": a, "end_ms": b, "duration_ms": b - a}
+                                                     for i, (a, b) in enumerate(zip(ts, ts[1:] + [end]))]}
+            else:
+                _, score = scene.ffmpeg_scene_scores(s_all, npx)
+                cut_ms = [int(float(scene.pts_time_string(int(c), tb_num, tb_den)) * 1000)
+                          for c in np.nonzero(score > float(scfg.get("threshold", 0.7)))[0]]
+                out["scene_detection"] = {"scenes": scene.build_scenes(cut_ms, duration_ms)}
+        logger.info(f"✅ Single-pass analysis complete: {frame_idx} frames (header: {total_frames}), "
+                    + ", ".join(f"{k}: {len(v.get('detections', v.get('scenes', [])))}" for k, v in out.items()))
+        return out
+
     # ---- scenes ----------------------------------------------------------------------------------------
     async def detect_scenes(self, video_path: str, config: dict) -> dict:
         """Scene boundaries.  Default = what the reference observes from

@@ -69,6 +69,21 @@ def hsv_sums(bgr_frames, prev=None, *, keep_on_device: bool = False) -> np.ndarr
     return _finish(out, keep_on_device)
 
 
+def luma_sad_bgr(bgr_frames, prev=None, *, keep_on_device: bool = False) -> np.ndarray:
+    """K1 on decoded BGR frames ``(n,h,w,3)``: OpenCV BT.601 luma of every pixel (``frames.bgr_to_luma_bt601``), then the
+    per-frame SAD; uint64 ``(n,)``, exact.  ``prev``: the BGR frame preceding frame 0 (same side of PCIe)."""
+    lib = _lib.load()
+    _lib.init()
+    n, h, w, c = (int(s) for s in bgr_frames.shape)
+    if c != 3:
+        raise ValueError("expected (n,h,w,3) BGR frames")
+    mem = same_side(bgr_frames, prev)
+    out = _out_like(bgr_frames, (n,))
+    _lib.check(lib.eioku_scene_sad_luma_bgr(ptr(bgr_frames), n, h, w, h * w * 3, ptr(prev), ptr(out), mem,
+                                            current_stream(bgr_frames)), "eioku_scene_sad_luma_bgr")
+    return _finish(out, keep_on_device)
+
+
 def bgr2hsv(bgr):
     """OpenCV-compatible 8-bit BGR->HSV image (parity/debug helper)."""
     lib = _lib.load()

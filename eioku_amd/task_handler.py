@@ -27,10 +27,13 @@ from uuid import uuid4
 logger = logging.getLogger(__name__)
 
 TASK_TO_ARTIFACT_TYPE = {"object_detection": "object.detection", "face_detection": "face.detection",
-                         "scene_detection": "scene"}
-TASK_TO_RESULT_KEY = {"object_detection": "detections", "face_detection": "detections", "scene_detection": "scenes"}
+                         "scene_detection": "scene", "segment_embedding": "segment.embedding"}
+TASK_TO_RESULT_KEY = {"object_detection": "detections", "face_detection": "detections", "scene_detection": "scenes",
+                      "segment_embedding": "embeddings"}
+# the reference's seven (task_handler.py:92-127) + the one its semantic-search design adds after transcription
+# (.kiro/specs/semantic-video-search/tasks.md:297-302): embed the transcript segments, index them
 KNOWN_TASK_TYPES = ("object_detection", "face_detection", "transcription", "ocr", "place_detection",
-                    "scene_detection", "metadata_extraction")
+                    "scene_detection", "metadata_extraction", "segment_embedding")
 
 
 @dataclass
@@ -104,6 +107,23 @@ def result_to_envelopes(result_dict: dict, task_id: str, task_type: str, video_i
     return envelopes
 
 
+def embed_segments(engine, video_id: str, segments: list[dict]) -> dict:
+    """The ``segment_embedding`` task body: K8 over the transcript segments, vectors into the store, one result row per
+    segment (span = the segment's, payload = text + 384 floats) for the artifact table."""
+    texts = [s["text"] for s in segments]
+    emb = engine.generator.generate_batch_embeddings(texts)
+    engine.store.delete_by_video_id(video_id)  # a re-run replaces the video's vectors, it does not duplicate them
+    meta, rows = [], []
+    for i, (s, e) in enumerate(zip(segments, emb)):
+        start_ms = int(s["start_ms"]) if "start_ms" in s else int(float(s.get("start", 0.0)) * 1000)
+        end_ms = int(s["end_ms"]) if "end_ms" in s else int(float(s.get("end", start_ms / 1000.0)) * 1000)
+        meta.append({"video_id": video_id, "start_time": start_ms / 1000.0, "end_time": end_ms / 1000.0, "text": s["text"],
+                     "thumbnail_path": s.get("thumbnail_path")})
+        rows.append({"start_ms": start_ms, "end_ms": end_ms, "text": s["text"], "embedding": [float(v) for v in e]})
+    engine.store.index_segments([f"{video_id}_seg{i}" for i in range(len(segments))], emb, meta)
+    return {"embeddings": rows}
+
+
 async def process_ml_task(ctx, task_id: str, task_type: str, video_id: str, video_path: str,
                           config: dict | None = None) -> dict:
     """Run one hot-path ML task and hand its artifacts to the sink.
@@ -132,6 +152,18 @@ async def process_ml_task(ctx, task_id: str, task_type: str, video_id: str, vide
             result = await model_manager.detect_faces(video_path, config or {})
         elif task_type == "scene_detection":
             result = await model_manager.detect_scenes(video_path, config or {})
+        elif task_type == "segment_embedding":
+            # segments: the transcription task's output for this video.  The reference would read them back from its
+            # artifact table; without a database they arrive in the job config or through ctx["segment_source"](video_id)
+            segments = (config or {}).get("segments")
+            if segments is None and ctx.get("segment_source"):
+                segments = ctx["segment_source"](video_id)
+            if segments is None:
+                raise ValueError("segment_embedding needs config['segments'] or ctx['segment_source']")
+            engine = ctx.get("search_engine")
+            if engine is None:
+                raise ValueError("segment_embedding needs ctx['search_engine'] (eioku_amd.semantic.SemanticSearchEngine)")
+            result = embed_segments(engine, video_id, segments)
         else:
             raise NotImplementedError(f"task type {task_type} is outside the MI355X hot path; route it to the "
                                       "reference worker")

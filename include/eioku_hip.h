@@ -104,6 +104,14 @@ int eioku_scene_sad_luma(const uint8_t* y_frames, int n, int h, int w, size_t ro
 int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t frame_stride,
                          const uint8_t* prev, uint64_t* sums_out, int mem, void* stream);
 
+/* K1 on decoded BGR frames, for the single-pass ingest entry (one upload of a frame serves scene + objects + faces):
+ * luma = OpenCV's 8-bit COLOR_BGR2YUV_I420 luma of each pixel (BT.601 studio range, 20-bit fixed point - what
+ * cv2.cvtColor gives for the frames cv2.VideoCapture.read() returns at model_manager.py:263), then the per-frame SAD of
+ * eioku_scene_sad_luma.  Exact uint64.  h * w must be a multiple of 4.  The DECODER's own Y plane differs from this by
+ * the YUV -> BGR -> Y round trip (+-1-2 codes on some pixels): use eioku_scene_sad_luma when that plane is available. */
+int eioku_scene_sad_luma_bgr(const uint8_t* bgr_frames, int n, int h, int w, size_t frame_stride, const uint8_t* prev,
+                             uint64_t* sad_out, int mem, void* stream);
+
 /* Debug / parity helper: the HSV image itself (same layout as the input). */
 int eioku_bgr2hsv(const uint8_t* bgr, size_t n_pixels, uint8_t* hsv_out, int mem, void* stream);
 

@@ -17,6 +17,10 @@ the hot path that exists as code under /root/reference:
                          parsing and the scene-list index quirk.
   ref_artifact_spans.json the span / validation rules of the result -> ArtifactEnvelope mapping
                          (ml-service/src/domain/artifacts.py:7-73) for rows produced by the path.
+  ref_projection_rows.json ProjectionSyncService.sync_artifact (services/projection_sync_service.py:26-330) run,
+                         one artifact at a time as task_handler.py:392-404 does, on an in-memory SQLite with the
+                         projection tables of backend/alembic (scene_ranges / object_labels / face_clusters): the
+                         envelopes fed in and the table rows that result - what the batched writer must reproduce.
 
 Only inputs and outputs are stored (JSON data); no reference source text is copied.
 The stubs stand in for cv2 / ultralytics / ffmpeg *calls*, i.e. the inputs of the orchestration
@@ -226,6 +230,56 @@ def capture_artifact_rules():
     return rows
 
 
+def capture_projection_rows():
+    """The reference's per-artifact projection upserts on SQLite: inputs (envelope fields) and resulting rows."""
+    from datetime import datetime
+
+    from sqlalchemy import create_engine, text
+    from sqlalchemy.orm import Session
+
+    from src.domain.artifacts import ArtifactEnvelope
+    from src.services.projection_sync_service import ProjectionSyncService
+
+    engine = create_engine("sqlite:///:memory:")
+    ddl = {  # columns of backend/alembic/versions/{c6f63e560f88,10a71bc9d989,325d54cd2340}_*.py
+        "scene_ranges": "artifact_id TEXT PRIMARY KEY, asset_id TEXT NOT NULL, scene_index INTEGER NOT NULL, start_ms INTEGER NOT NULL, end_ms INTEGER NOT NULL",
+        "object_labels": "artifact_id TEXT PRIMARY KEY, asset_id TEXT NOT NULL, label TEXT NOT NULL, confidence REAL NOT NULL, start_ms INTEGER NOT NULL, end_ms INTEGER NOT NULL",
+        "face_clusters": "artifact_id TEXT PRIMARY KEY, asset_id TEXT NOT NULL, cluster_id TEXT, confidence REAL NOT NULL, start_ms INTEGER NOT NULL, end_ms INTEGER NOT NULL",
+    }
+    payloads = [
+        ("scene", {"scene_index": 0, "start_ms": 0, "end_ms": 6600, "duration_ms": 6600}, 0, 6600),
+        ("scene", {"scene_index": 2, "start_ms": 6600, "end_ms": 7666, "duration_ms": 1066}, 6600, 7666),
+        ("scene", {"start_ms": 1, "end_ms": 2}, 1, 2),  # no scene_index -> default 0
+        ("object.detection", {"frame_index": 0, "timestamp_ms": 0, "label": "person", "confidence": 0.8999999761581421,
+                              "bbox": {"x": 1.5, "y": 2.0, "width": 10.0, "height": 20.0}}, 0, 0),
+        ("object.detection", {"frame_index": 89, "timestamp_ms": 2969, "label": "dog", "confidence": 0.5123,
+                              "bbox": {"x": 0.0, "y": 0.0, "width": 1.0, "height": 1.0}}, 2969, 2969),
+        ("object.detection", {"frame_index": 178, "timestamp_ms": 5939}, 5939, 5939),  # no label / confidence -> "" / 0.0
+        ("face.detection", {"frame_index": 0, "timestamp_ms": 0, "label": "face", "confidence": 0.91, "cluster_id": None,
+                            "bbox": {"x": 3.0, "y": 4.0, "width": 5.0, "height": 6.0}}, 0, 0),
+        ("face.detection", {"frame_index": 90, "timestamp_ms": 3000, "label": "face", "confidence": 0.75, "cluster_id": "c7",
+                            "bbox": {"x": 3.0, "y": 4.0, "width": 5.0, "height": 6.0}}, 3000, 3000),
+        ("object.detection", {"frame_index": 0, "timestamp_ms": 0, "label": "cat", "confidence": 0.66}, 0, 0),  # same id as row 3: upsert
+        ("segment.embedding", {"text": "hello", "embedding": [0.1, 0.2]}, 10, 20),  # no projection table
+    ]
+    ids = ["vid_scene_r_0", "vid_scene_r_1", "vid_scene_r_2", "vid_object_detection_r_0", "vid_object_detection_r_1",
+           "vid_object_detection_r_2", "vid_face_detection_r_0", "vid_face_detection_r_1", "vid_object_detection_r_0", "vid_seg_r_0"]
+    envs = []
+    with Session(engine) as session:
+        for table, cols in ddl.items():
+            session.execute(text(f"CREATE TABLE {table} ({cols})"))
+        svc = ProjectionSyncService(session)
+        for aid, (atype, payload, a, b) in zip(ids, payloads):
+            env = ArtifactEnvelope(artifact_id=aid, asset_id="vid", artifact_type=atype, schema_version=1, span_start_ms=a,
+                                   span_end_ms=b, payload_json=json.dumps(payload), producer="ml-service", producer_version="1.0.0",
+                                   model_profile="balanced", config_hash="", input_hash="", run_id="r", created_at=datetime(2026, 1, 28))
+            svc.sync_artifact(env)  # one statement per artifact, as task_handler.py:392-404
+            envs.append({"artifact_id": aid, "artifact_type": atype, "span_start_ms": a, "span_end_ms": b, "payload": payload})
+        session.flush()
+        tables = {t: [list(r) for r in session.execute(text(f"SELECT * FROM {t} ORDER BY artifact_id")).fetchall()] for t in ddl}
+    return {"ddl": ddl, "envelopes": envs, "tables": tables}
+
+
 def main():
     if not REF.exists():
         sys.exit("needs /root/reference (build container only)")
@@ -235,8 +289,19 @@ def main():
     (HERE / "ref_detect_loop.json").write_text(json.dumps(capture_detect_loop(ModelManager), indent=1))
     (HERE / "ref_scenes.json").write_text(json.dumps(capture_scenes(ModelManager), indent=1))
     (HERE / "ref_artifact_spans.json").write_text(json.dumps(capture_artifact_rules(), indent=1))
+    (HERE / "ref_projection_rows.json").write_text(json.dumps(capture_projection_rows(), indent=1) + "\n")
     print("wrote fixtures to", HERE)
 
 
+def main_projection_only():
+    sys.path.insert(0, str(REF))
+    out = capture_projection_rows()
+    (HERE / "ref_projection_rows.json").write_text(json.dumps(out, indent=1) + "\n")
+    print("wrote ref_projection_rows.json:", {k: len(v) for k, v in out["tables"].items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "projection":
+        main_projection_only()
+        sys.exit(0)
     main()
