@@ -493,13 +493,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_flat(ConvArgs a, int npix, i
   u32x4 sreg[NS], wreg[WREG];
   const bool cin_tail = (a.Cin & 31) != 0;
   auto fetch = [&](int cc) {
-    const __half* src = a.in + cc * 32;
+    // a unit past Cin (Cin = 48, 80, ...) reads element 0 instead: at the last pixel of the tensor the real address
+    // would lie past the end of the allocation (an unmapped page when the buffer ends on a page boundary)
+    const bool past = cin_tail && cc * 32 + (tid & 3) * 8 >= a.Cin;
+    const __half* src = a.in + (past ? 0 : cc * 32);
 #pragma unroll
-    for (int j = 0; j < NS; ++j) sreg[j] = *reinterpret_cast<const u32x4*>(src + s_g[j]);
+    for (int j = 0; j < NS; ++j) sreg[j] = *reinterpret_cast<const u32x4*>(src + (past ? 0 : s_g[j]));
 #pragma unroll
     for (int j = 0; j < WREG; ++j)
       if (WT_U % 256 == 0 || tid + j * 256 < WT_U) wreg[j] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)cc * WT_U + j * 256);
-    if (cin_tail && cc * 32 + (tid & 3) * 8 >= a.Cin) {  // channels past Cin (weights there are zero; the data may be anything)
+    if (past) {  // channels past Cin (weights there are zero; the data may be anything)
 #pragma unroll
       for (int j = 0; j < NS; ++j) sreg[j] = u32x4{0, 0, 0, 0};
     }

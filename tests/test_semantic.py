@@ -78,8 +78,10 @@ SEGMENTS = [{"text": "the cat sat on the mat", "start": 0.0, "end": 2.5}, {"text
 
 
 @pytest.mark.gpu
-def test_segment_embedding_task_and_semantic_search_end_to_end(gpu, vocab_file, tmp_path):
+def test_segment_embedding_task_and_semantic_search_end_to_end(gpu, vocab_file, tmp_path, monkeypatch):
     from eioku_amd import embed
+
+    monkeypatch.setenv("MODEL_CACHE_DIR", str(tmp_path / "models"))  # the reference default, /models, is the container's
     from oracle import bert as obert
 
     cfg = dict(embed.MINILM_L6_V2, vocab=64)
