@@ -893,8 +893,6 @@ void launch_add_ln(const float* a, int nsplit, const float* abias, const float* 
 // of an [M x 384] output is ~100 workgroups on 256 CUs, each walking all of K serially; `splits` planes of
 // partial sums (summed, in plane order, by k_add_ln) put 2-4x as many workgroups on the chip.
 int pick_splits(int M, int N, int K) {
-  static const int forced = getenv("EIOKU_GEMM_SPLITS") ? atoi(getenv("EIOKU_GEMM_SPLITS")) : 0;  // A/B switch
-  if (forced > 0 && K % (128 * forced) == 0) return forced;
   if (M >= 8192) return 1;
   const int blocks = ((M + 63) / 64) * (N / 64);
   if (K % 128 == 0) {  // k_gemm_f32_s: stages of 128; the largest split <= kMaxSplit that divides them evenly
@@ -918,8 +916,9 @@ int gemm(const float* A, int lda, const float* W, const float* bias, float* C, i
   const int kchunks = K / kBK / splits;
   if (splits > 1) bias = nullptr;
   prof_start(EIOKU_PROF_GEMM, stream);
-  static const bool bf_all = !(getenv("EIOKU_GEMM_BF16") && atoi(getenv("EIOKU_GEMM_BF16")) == 0) &&
-                             !(getenv("EIOKU_GEMM_BF16_LARGE") && atoi(getenv("EIOKU_GEMM_BF16_LARGE")) == 0);
+  // EIOKU_GEMM_BF16=0 / EIOKU_GEMM_S=0 / EIOKU_ATTN_MFMA=0 route the encoder through the fp32-FMA kernels (the
+  // numerics cross-check of tests/test_bert_gpu.py::test_fp32_fma_route_matches_the_mfma_route)
+  static const bool bf_all = !(getenv("EIOKU_GEMM_BF16") && atoi(getenv("EIOKU_GEMM_BF16")) == 0);
   if (M >= 8192 && !(bf_all && K % (128 * splits) == 0)) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)(N / 128), (unsigned)splits);
     if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
@@ -937,8 +936,7 @@ int gemm(const float* A, int lda, const float* W, const float* bias, float* C, i
     // per workgroup instead of 64.  The GEMM alone is as fast (0.457 vs 0.460 ms per 8 x 128 tokens) but two of its
     // workgroups no longer take 128 of a CU's 160 KB away from the conv kernels on the other streams: +1.5 % on the
     // overlapped step.  Same k order, so the results are bit-identical.
-    static const int bks_env = getenv("EIOKU_GEMM_BKS") ? atoi(getenv("EIOKU_GEMM_BKS")) : 0;
-    const bool bks64 = bks_env == 64 || (bks_env == 0 && M < 8192);
+    const bool bks64 = M < 8192;
     const int kstages = K / 128 / splits;
     static const bool bf = !(getenv("EIOKU_GEMM_BF16") && atoi(getenv("EIOKU_GEMM_BF16")) == 0);
     static bool attr2 = false;

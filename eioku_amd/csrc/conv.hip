@@ -75,7 +75,8 @@ __device__ __forceinline__ float silu_f32(float v) {
 // Four values at once, the same operations bit for bit (__expf(-v) compiles to v_exp_f32(v * -log2e), the constant
 // being float(log2 e) = 0x3fb8aa3b): written on vectors so that the multiply and the +1 become v_pk_mul_f32 /
 // v_pk_add_f32 (two values per issue slot).  The epilogues of the shallow layers are VALU-bound, not MFMA-bound:
-// 918 VALU instructions per 67 MFMAs in k_conv_stem_chain, a third of them SiLU.
+// 745 VALU instructions per 67 MFMAs in k_conv_stem_chain, a third of them SiLU.  (Plain v_mul_f32 / v_add_f32
+// instead of the packed forms measured SLOWER here: stem chain 126.8 -> 132.8 us, chain<1> 93.0 -> 96.7 us.)
 __device__ __forceinline__ float4v silu4(float4v v) {
   const float4v t = v * float4v{-1.44269504088896340736f, -1.44269504088896340736f, -1.44269504088896340736f,
                                 -1.44269504088896340736f};
@@ -1662,8 +1663,7 @@ int launch_persist(const ConvArgs& a_in, int ntiles, hipStream_t stream) {
   a.tiles_h = (a.Ho + TH - 1) / TH;
   const int total = a.tiles_w * a.tiles_h * a.N;
   // 160 KB of LDS per CU: two 78 KB workgroups do fit (measured on model.22.cv3.0.0, 68 -> 57 us)
-  static const int cu_kb = getenv("EIOKU_LDS_CU_KB") ? atoi(getenv("EIOKU_LDS_CU_KB")) : 160;
-  int per_cu = (int)((size_t)cu_kb * 1024 / lds);
+  int per_cu = (int)((size_t)160 * 1024 / lds);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
   int bx = num_cus() * per_cu / ntiles;
@@ -1686,11 +1686,10 @@ template <int S>
 int launch_persist_dispatch(int nf, int nch, bool db, const ConvArgs& a, int ntiles, hipStream_t stream, bool* handled) {
   *handled = true;
   // weight block too large for two workgroups per CU: one 8-wave workgroup with a 16x16 tile (two waves per SIMD)
-  static const bool w8_off = getenv("EIOKU_PERSIST_W8") && atoi(getenv("EIOKU_PERSIST_W8")) == 0;
-  if (S == 1 && !db && !w8_off && nf == 3 && nch == 3 && persist_lds(nf, S, nch, false) > 80 * 1024 &&
+  if (S == 1 && !db && nf == 3 && nch == 3 && persist_lds(nf, S, nch, false) > 80 * 1024 &&
       persist_lds(nf, S, nch, false, 16) <= 160 * 1024 && a.Ho > 8)
     return launch_persist<3, S, 3, false, false, 8>(a, ntiles, stream);
-  if (S == 1 && !db && !w8_off && nf == 5 && nch == 2 && a.Ho > 8) return launch_persist<5, S, 2, false, false, 8>(a, ntiles, stream);
+  if (S == 1 && !db && nf == 5 && nch == 2 && a.Ho > 8) return launch_persist<5, S, 2, false, false, 8>(a, ntiles, stream);
 #define EIOKU_P(NF_, NCH_)                                                                    \
   if (nf == NF_ && nch == NCH_)                                                                \
     return db ? launch_persist<NF_, S, NCH_, true>(a, ntiles, stream) : launch_persist<NF_, S, NCH_, false>(a, ntiles, stream);
@@ -1707,12 +1706,9 @@ int launch_persist_dispatch(int nf, int nch, bool db, const ConvArgs& a, int nti
 template <int S>
 int launch_persist_post_dispatch(int nf, int nch, bool db, const ConvArgs& a, hipStream_t stream, bool* handled) {
   *handled = true;
-  // stride-2, 64 couts (model.3 -> model.4.cv1): 98 KB of LDS = one 4-wave workgroup per CU; the 8-wave 16x16-tile
-  // variant (149 KB) puts two waves on every SIMD: 54 -> 50 us alone, but the overlapped step is slower (41.8 vs 42.2 k
-  // frames/s: 149 KB leave no LDS for the other streams' workgroups), so it stays opt-in (EIOKU_POST_W8=1)
-  static const bool w8_off = getenv("EIOKU_PERSIST_W8") && atoi(getenv("EIOKU_PERSIST_W8")) == 0;
-  static const bool pw8 = getenv("EIOKU_POST_W8") && atoi(getenv("EIOKU_POST_W8")) != 0;
-  if (S == 2 && nf == 4 && nch == 1 && !db && !w8_off && pw8 && a.Ho > 8) return launch_persist<4, S, 1, false, true, 8>(a, 1, stream);
+  // stride-2, 64 couts (model.3 -> model.4.cv1): 98 KB of LDS = one 4-wave workgroup per CU.  An 8-wave 16x16-tile
+  // variant (149 KB, two waves on every SIMD) measured 54 -> 50 us alone but a slower overlapped step (41.8 vs 42.2 k
+  // frames/s: 149 KB leave no LDS for the other streams' workgroups) and was removed.
 #define EIOKU_PP(NF_, NCH_)                                                                             \
   if (nf == NF_ && nch == NCH_)                                                                          \
     return db ? launch_persist<NF_, S, NCH_, true, true>(a, 1, stream) : launch_persist<NF_, S, NCH_, false, true>(a, 1, stream);
@@ -1790,8 +1786,6 @@ int launch_flat_dispatch(int nf, const ConvArgs& a, int ntiles, hipStream_t stre
   *handled = false;
   // 32-bit element offsets; pixel / virtual-row indices below 2^24 (fast_div)
   if ((long long)a.N * a.H * a.W * a.in_cs >= (1ll << 31) || (long long)a.N * (a.H + 1) * (a.W + 2) >= (1ll << 24)) return EIOKU_OK;
-  static const bool off = getenv("EIOKU_CONV_FLAT") && atoi(getenv("EIOKU_CONV_FLAT")) == 0;
-  if (off) return EIOKU_OK;
   int mt = 2;
   FlatGeom g = flat_geom<S>(a, nf, mt);
   if (g.slots > 8 || g.lds > 80 * 1024) {
@@ -1871,13 +1865,7 @@ int launch1x1_impl(const ConvArgs& a, int ntiles, int wg_cu, hipStream_t stream)
 // 64 MFMAs per pixel group and wave) are best with ONE workgroup per CU.
 template <int NF>
 int launch1x1(const ConvArgs& a, int ntiles, hipStream_t stream) {
-  static const int wg_env = getenv("EIOKU_1X1_WG") ? atoi(getenv("EIOKU_1X1_WG")) : 0;
-  static const int w8_env = getenv("EIOKU_1X1_W8") ? atoi(getenv("EIOKU_1X1_W8")) : 0;
-  const long long groups = ((long long)a.N * a.H * a.W + 31) / 32;
-  const bool fills = groups * ntiles / 8 >= (long long)num_cus() * 3 / 4;  // an 8-wave workgroup for (nearly) every CU
-  const bool w8 = fills && ((NF >= 8 && w8_env >= 1) || w8_env >= 2);
-  const int wg = wg_env > 0 ? wg_env : ((NF >= 8 || w8) ? 1 : 2);
-  if (w8) return a.in2 ? launch1x1_impl<NF, true, 8>(a, ntiles, wg, stream) : launch1x1_impl<NF, false, 8>(a, ntiles, wg, stream);
+  const int wg = NF >= 8 ? 1 : 2;
   return a.in2 ? launch1x1_impl<NF, true, 4>(a, ntiles, wg, stream) : launch1x1_impl<NF, false, 4>(a, ntiles, wg, stream);
 }
 
@@ -1898,17 +1886,14 @@ int launch1x1_nf(int nf, const ConvArgs& a, int ntiles, hipStream_t stream) {
 // Fewest padded channels first, then the widest tile (fewer re-reads of the input patch).
 int pick_nf(int cout, int ks, int nchunks, int stride) {
   const int frags = (cout + 15) / 16;
-  // 64 -> 80 (the class branch's first conv at P3): all 80 couts in one 8-wave workgroup (134 KB), the input staged
-  // once and no padded fragment, instead of 48 + 32 couts in two 78 KB workgroups.  Measured: 56.2 vs 56.7 us alone,
-  // 41.3 vs 41.3 k frames/s overlapped -- no gain, opt-in only (EIOKU_NF5=1)
-  static const bool nf5 = getenv("EIOKU_NF5") && atoi(getenv("EIOKU_NF5")) != 0;
-  if (nf5 && ks == 3 && stride == 1 && nchunks == 2 && frags == 5) return 5;
+  // (64 -> 80, the class branch's first conv at P3, as ONE 5-fragment 8-wave workgroup of 134 KB instead of 48 + 32
+  // couts in two 78 KB workgroups measured no gain: 56.2 vs 56.7 us alone, 41.3 vs 41.3 k frames/s overlapped)
   if (ks == 3 && nchunks <= 3) {
     // persistent kernel: largest tile (<= 4 fragments, no padding waste beyond one fragment) that still fits
     // two workgroups per CU with a single-buffered patch; otherwise fall through to the generic rule
     for (int nf : {4, 3, 2, 1}) {
       const int waste = ((frags + nf - 1) / nf) * nf - frags;
-      static const int lim_kb = getenv("EIOKU_PERSIST_KB") ? atoi(getenv("EIOKU_PERSIST_KB")) : 79;  // two workgroups per 160 KB CU
+      constexpr int lim_kb = 79;  // two workgroups per 160 KB CU
       if (waste <= (frags >= 4 ? 1 : 0) && persist_lds(nf, stride, nchunks, false) <= (size_t)lim_kb * 1024) {
         // a 1-fragment tile re-reads the halo patch once per 16 couts and is LDS-read bound (3 reads per 2
         // MFMAs): with >= 5 fragments take 3 per tile even if only one workgroup then fits per CU
@@ -1924,7 +1909,7 @@ int pick_nf(int cout, int ks, int nchunks, int stride) {
     // 64 KB: with 96-128 KB tiles (NF = 8, 8 waves) the 384/512-channel 1x1 layers are 2-4 us faster each in an
     // isolated trace (-26 us per forward) but the overlapped step is not (40.5 vs 40.4 k frames/s) and the serial
     // profiled step is slower: a workgroup holding most of a CU's LDS keeps the other streams' kernels off that CU
-    static const int lim1 = getenv("EIOKU_1X1_KB") ? atoi(getenv("EIOKU_1X1_KB")) : 64;
+    constexpr int lim1 = 64;
     if (ks == 1 && nf * nchunks > lim1 && nf > 1) continue;  // 1x1: the whole Cin x tile weight block lives in LDS (nf*nchunks KB)
     int waste = ((frags + nf - 1) / nf) * nf - frags;
     if (waste < best_waste) {
@@ -2070,16 +2055,15 @@ int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, i
     cc.cat_cs = cat_in.cstride;
   }
   prof_start(EIOKU_PROF_CONV, stream);
-  static const int db_env = getenv("EIOKU_CHAIN_DB") ? atoi(getenv("EIOKU_CHAIN_DB")) : -1;
-  const bool db = db_env > 0;  // measured: the extra workgroup per CU beats the second patch buffer (69 vs 77 us at 160^2)
+  // (a second patch buffer was measured against an extra workgroup per CU: 77 vs 69 us at 160^2; single-buffered it is)
   int rc;
   if (cat_w) {
     const int cat = chain_cat_chunks(ca, *cat_w);
     rc = cat == 1 ? launch_chain<1, false, 1, 2>(a, cc, stream)
                   : (cat == 2 ? launch_chain<2, false, 2, 4>(a, cc, stream) : launch_chain<2, false, 3, 4>(a, cc, stream));
   }
-  else if (ca.nf == 1) rc = db ? launch_chain<1, true>(a, cc, stream) : launch_chain<1, false>(a, cc, stream);
-  else rc = db ? launch_chain<2, true>(a, cc, stream) : launch_chain<2, false>(a, cc, stream);
+  else if (ca.nf == 1) rc = launch_chain<1, false>(a, cc, stream);
+  else rc = launch_chain<2, false>(a, cc, stream);
   prof_stop(EIOKU_PROF_CONV, stream);
   return rc;
 }
@@ -2131,9 +2115,7 @@ int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, cons
     attr_set = true;
   }
   const int total = a.tiles_w * a.tiles_h * N;
-  int per_cu = (int)(150 * 1024 / kStemChainLds);
-  static const int per_cu_env = getenv("EIOKU_STEM_CHAIN_WG") ? atoi(getenv("EIOKU_STEM_CHAIN_WG")) : 0;
-  if (per_cu_env > 0) per_cu = per_cu_env;
+  const int per_cu = (int)(150 * 1024 / kStemChainLds);
   int bx = num_cus() * per_cu;
   if (bx > total) bx = total;
   prof_start(EIOKU_PROF_CONV, stream);
@@ -2228,7 +2210,7 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
   // maps too small for 8x16 tiles (20x20: 52 % of a tiling is outside the map): flattened-pixel tiles whatever
   // the depth.  Measured: 80->80 @20 19.8 -> 13.8 us, 64->64 @20 13.2 -> 10.5; at 40x40 resident weights still
   // win (64->64 20.7 vs 25.8 us), hence the 24-pixel cut.
-  static const int flat_wo = getenv("EIOKU_FLAT_WO") ? atoi(getenv("EIOKU_FLAT_WO")) : 24;
+  constexpr int flat_wo = 24;
   if (!handled && cw.ks == 3 && cw.nchunks >= 2 && cw.nchunks <= 3 && a.Wo <= flat_wo)
     rc = cw.stride == 1 ? launch_flat_dispatch<1>(cw.nf, a, cw.ntiles, stream, &handled)
                         : launch_flat_dispatch<2>(cw.nf, a, cw.ntiles, stream, &handled);

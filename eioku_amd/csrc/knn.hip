@@ -1257,9 +1257,8 @@ int legacy_search(eioku_index* ix, const float* dq, int nq, int k, const float* 
   if (prof) prof_start(EIOKU_PROF_KNN, stream);
   // wide searches (nq > 64) with k <= 16 over d in {128, 256, 384}: split-bf16 kernel (see k_flat_l2_bf); a bounded
   // search (lbd) stays on the exact-fp32 kernels so that successive rounds see bit-identical distances
-  static const bool bf_off = getenv("EIOKU_KNN_BF16") && atoi(getenv("EIOKU_KNN_BF16")) == 0;
   rc = -1;
-  if (wide && K == 16 && !bf_off && !lbd) rc = launch_search_bf<16>(d, a, grid, stream);
+  if (wide && K == 16 && !lbd) rc = launch_search_bf<16>(d, a, grid, stream);
   if (rc != -1) {
   } else if (K == 1) rc = wide ? launch_search_k<1, true>(d, a, grid, stream) : launch_search_k<1, false>(d, a, grid, stream);
   else if (wide) rc = K == 16 ? launch_search_k<16, true>(d, a, grid, stream) : launch_search_k<32, true>(d, a, grid, stream);

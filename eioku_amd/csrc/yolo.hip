@@ -90,21 +90,6 @@ struct eioku_yolo {
   void* lb_key_ptr = nullptr;
   __half* lb_out = nullptr;  // == bufs[in_buf].ptr
   double conv_flops_last = 0;
-  // The ~80 launches of one forward replayed as a hipGraph (same shapes, same buffers, same source frames):
-  // the network's small low-resolution layers are 10-20 us each, so the 2-4 us between dependent launches are a
-  // tenth of a step.  `gen` moves whenever anything a recorded kernel argument points at can have changed.
-  struct NetGraph {
-    hipGraphExec_t exec = nullptr;
-    hipGraph_t graph = nullptr;
-    int n = 0, h = 0, w = 0;
-    bool fused = false;
-    unsigned long long gen = ~0ull;
-    double flops = 0;
-  } net_graph;
-  unsigned long long gen = 0;        // bumped by set_conv and by every (re)allocation in prepare()
-  int eager_runs_at_key = 0;         // a shape is captured on its second consecutive run (the first one warms
-  int key_n = 0, key_h = 0, key_w = 0;  // function attributes and allocations, which capture must not see)
-  hipStream_t cap_stream = nullptr;  // capture happens on a private stream; replay on the caller's
 };
 
 namespace {
@@ -306,14 +291,6 @@ int ensure(T** p, size_t* cap, size_t bytes) {
   return EIOKU_OK;
 }
 
-void drop_graph(eioku_yolo* y) {
-  auto& g = y->net_graph;
-  if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  if (g.graph) (void)hipGraphDestroy(g.graph);
-  g.exec = nullptr;
-  g.graph = nullptr;
-}
-
 int prepare(eioku_yolo* y, int n, int h, int w) {
   EIOKU_REQUIRE(h % 32 == 0 && w % 32 == 0, "network input %dx%d must be a multiple of 32", h, w);
   // the conv kernels address activations with 32-bit element offsets and decode tile / pixel indices below 2^24
@@ -324,7 +301,6 @@ int prepare(eioku_yolo* y, int n, int h, int w) {
                   "batch of %d frames at %dx%d: an activation tensor of %lld x %d channels exceeds one launch's 32-bit "
                   "offsets -- split the batch", n, h, w, px, b.ch);
   }
-  if (n != y->cur_n || h != y->cur_h || w != y->cur_w) y->gen++;  // buffers may move below
   for (auto& b : y->bufs) {
     const size_t bytes = (size_t)n * level_dim(h, b.level) * level_dim(w, b.level) * b.ch * sizeof(__half);
     int rc = ensure(&b.ptr, &b.cap, bytes);
@@ -382,15 +358,12 @@ int record_pass_rate(eioku_yolo* y, int n, int A, hipStream_t stream) {
   return EIOKU_OK;
 }
 
-// part: 0 = every op, 1 = the first op only, 2 = all but the first
 int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedInput* fused, double* flops_out,
-            int part = 0, bool clsmax = false, bool lazybox = false, bool lazydeep = false) {
+            bool clsmax = false, bool lazybox = false, bool lazydeep = false) {
   double flops = 0;
   bool skip_next = false;
   int pool_skip = 0, front_skip = 0;
   for (const Op& op : y->ops) {
-    const bool is_first = &op == &y->ops.front();
-    if ((part == 1 && !is_first) || (part == 2 && is_first)) continue;
     if (front_skip > 0) {  // ran inside the fused front-end launch
       --front_skip;
       continue;
@@ -421,7 +394,7 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
                         nx->f32_out < 0 && nx->in_buf == op.out_buf && nx->in_off == op.out_off && op.sole_consumer &&
                         conv_post_ok(cw, y->weights[nx->conv]);
       // fused-letterbox stem -> model.1 -> model.2.cv1 (YOLOv8n, copy-mode frames): one launch
-      if (first && fused && part == 0 && y->ops.size() > 2) {
+      if (first && fused && y->ops.size() > 2) {
         const Op& o1 = y->ops[1];
         const Op& o2 = y->ops[2];
         const bool front = o1.kind == kConv && o2.kind == kConv && op.f32_out < 0 && op.res_buf < 0 && o1.f32_out < 0 &&
@@ -550,62 +523,9 @@ int run_network(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const Fu
                 bool clsmax = false, bool lazybox = false, bool lazydeep = false) {
   for (size_t i = 0; i < y->set.size(); ++i)
     EIOKU_REQUIRE(y->set[i], "conv %zu (%s) has no weights", i, y->names[i].c_str());
-  // opt-in (EIOKU_GRAPH=1): on ROCm 7.2 / MI355X replaying the forward as a graph measured 3.07 ms per bench step
-  // against 3.03 ms for plain launches -- the gaps between dependent kernels are the GPU's, not the host's
-  static const bool graphs = getenv("EIOKU_GRAPH") && atoi(getenv("EIOKU_GRAPH")) == 1;
-  auto& g = y->net_graph;
-  // eager whenever the per-launch event hooks are on (events recorded inside a graph cannot be read back)
-  if (!graphs || prof_enabled() || n == 0 || clsmax) return run_ops(y, n, h, w, stream, fused, &y->conv_flops_last, 0, clsmax, lazybox, lazydeep);
-  // a fused stem reads the CALLER's frames: it stays an ordinary launch so that the graph only ever points at
-  // this handle's own buffers and weights
-  double flops0 = 0;
-  const int gpart = fused ? 2 : 0;
-  const bool hit = g.exec && g.gen == y->gen && g.n == n && g.h == h && g.w == w && g.fused == (fused != nullptr);
-  if (hit) {
-    if (fused) {
-      const int rc = run_ops(y, n, h, w, stream, fused, &flops0, 1);
-      if (rc) return rc;
-    }
-    EIOKU_HIP_CHECK(hipGraphLaunch(g.exec, stream));
-    y->conv_flops_last = g.flops + flops0;
-    return EIOKU_OK;
-  }
-  if (y->key_n != n || y->key_h != h || y->key_w != w) {
-    y->key_n = n;
-    y->key_h = h;
-    y->key_w = w;
-    y->eager_runs_at_key = 0;
-  }
-  if (y->eager_runs_at_key++ < 1) return run_ops(y, n, h, w, stream, fused, &y->conv_flops_last);
-  // capture on a private stream (the caller's may be the legacy default stream, which cannot be captured)
-  if (!y->cap_stream) EIOKU_HIP_CHECK(hipStreamCreateWithFlags(&y->cap_stream, hipStreamNonBlocking));
-  drop_graph(y);
-  if (fused) {
-    const int rc0 = run_ops(y, n, h, w, stream, fused, &flops0, 1);
-    if (rc0) return rc0;
-  }
-  EIOKU_HIP_CHECK(hipStreamBeginCapture(y->cap_stream, hipStreamCaptureModeThreadLocal));
-  double flops = 0;
-  const int rc = run_ops(y, n, h, w, y->cap_stream, nullptr, &flops, gpart);
-  const hipError_t ce = hipStreamEndCapture(y->cap_stream, &g.graph);
-  if (rc) {
-    drop_graph(y);
-    return rc;
-  }
-  if (ce != hipSuccess || hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    drop_graph(y);
-    const int rc2 = run_ops(y, n, h, w, stream, nullptr, &flops, gpart);  // capture unavailable: stay eager
-    y->conv_flops_last = flops + flops0;
-    return rc2;
-  }
-  g.n = n; g.h = h; g.w = w;
-  g.fused = fused != nullptr;
-  g.gen = y->gen;
-  g.flops = flops;
-  EIOKU_HIP_CHECK(hipGraphLaunch(g.exec, stream));
-  y->conv_flops_last = flops + flops0;
-  return EIOKU_OK;
+  // (replaying the forward as a hipGraph was built and measured on ROCm 7.2 / MI355X: 3.07 ms per bench step against
+  // 3.03 ms for plain launches -- the gaps between dependent kernels are the GPU's, not the host's -- and removed)
+  return run_ops(y, n, h, w, stream, fused, &y->conv_flops_last, clsmax, lazybox, lazydeep);
 }
 
 }  // namespace
@@ -630,8 +550,6 @@ int eioku_yolo_create(const int* ch5, const int* depth4, int nc, eioku_yolo** ou
 void eioku_yolo_destroy(eioku_yolo* y) {
   if (!y) return;
   (void)hipDeviceSynchronize();
-  drop_graph(y);
-  if (y->cap_stream) (void)hipStreamDestroy(y->cap_stream);
   for (auto& w : y->weights) conv_weights_destroy(&w);
   for (auto& b : y->bufs)
     if (b.ptr) (void)hipFree(b.ptr);
@@ -668,7 +586,6 @@ int eioku_yolo_set_conv(eioku_yolo* y, int idx, const float* w_oihw, const float
   EIOKU_REQUIRE(y && idx >= 0 && idx < (int)y->names.size(), "bad conv index %d", idx);
   EIOKU_REQUIRE(w_oihw, "NULL weights");
   const auto& s = y->shapes[idx];
-  y->gen++;
   if (y->set[idx]) conv_weights_destroy(&y->weights[idx]);
   int rc = conv_weights_create(&y->weights[idx], s[0], s[1], s[2], s[3], w_oihw, bias);
   y->set[idx] = rc == EIOKU_OK;

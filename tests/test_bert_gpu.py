@@ -118,3 +118,32 @@ def test_full_size_batch_invariance(gpu):
     again = enc.encode_ids(ids[:8], mask[:8])
     assert np.array_equal(small, again)                       # split-K planes are summed in plane order
     enc.close()
+
+
+def test_fp32_fma_route_matches_the_mfma_route(gpu, tmp_path):
+    """The library keeps its fp32-FMA GEMM / attention kernels reachable (EIOKU_GEMM_BF16=0, EIOKU_GEMM_S=0,
+    EIOKU_ATTN_MFMA=0; read once per process): the same golden inputs through that route meet the same bar, and the
+    two routes agree far inside it -- an independent check on the split-bf16 MFMA numerics."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from eioku_amd import embed\n"
+        "g = np.load(%r)\n"
+        "cfg = dict(embed.MINILM_L6_V2, vocab=int(g['vocab']))\n"
+        "enc = embed.MiniLMEncoder(embed.random_state(cfg, int(g['seed'])), cfg)\n"
+        "np.save(sys.argv[1], enc.encode_ids(g['ids'], g['mask']))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(GOLDEN / "minilm_seed11.npz"))
+    want = np.load(GOLDEN / "minilm_seed11.npz")["out"]
+    outs = {}
+    for name, env in {"mfma": {}, "fma": {"EIOKU_GEMM_BF16": "0", "EIOKU_GEMM_S": "0", "EIOKU_ATTN_MFMA": "0"},
+                      "fma_s": {"EIOKU_GEMM_BF16": "0"}}.items():
+        path = tmp_path / f"{name}.npy"
+        subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=dict(os.environ, **env), timeout=300)
+        outs[name] = np.load(path)
+        assert _close(outs[name], want), (name, float(np.abs(outs[name] - want).max()))
+    assert np.abs(outs["mfma"] - outs["fma"]).max() <= 2e-5
+    assert np.abs(outs["fma_s"] - outs["fma"]).max() <= 2e-5

@@ -284,6 +284,45 @@ def test_lazy_and_dense_box_branch_give_identical_detections(gpu, tmp_path):
         assert np.array_equal(a, b)
 
 
+def test_detect_fusion_switches_leave_the_detections_byte_identical(gpu, tmp_path):
+    """Every detect()-level fusion the library keeps a switch for (each read once per process): the one-launch
+    YOLOv8n front end (EIOKU_STEM_CHAIN), the stem reading the BGR frames itself (EIOKU_STEM_FUSE), the class head
+    writing {max logit, argmax} words instead of 80 logits (EIOKU_CLSMAX) and the lazily evaluated box branch
+    (EIOKU_LAZY_BOX).  640-wide copy-mode sources so that all of them are eligible; the detections of every
+    variant must be the all-on bytes."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from eioku_amd import detect as D, weights as W\n"
+        "from oracle import prng\n"
+        "f = torch.from_numpy(prng.synth_frames_bgr(43, 4, 480, 640)).cuda()\n"
+        "det = D.Yolov8Detector('n', 80, W.random_state('n', 80, seed=9))\n"
+        "det.calibrate_random_head(f, frac=0.01)\n"
+        "out = []\n"
+        "for _ in range(2):\n"
+        "    d, c = det.detect(f, conf=0.25)\n"
+        "    torch.cuda.synchronize()\n"
+        "    out += [d.view(np.uint8).reshape(len(c), -1)[i, :32 * c[i]] for i in range(len(c))] + [c]\n"
+        "np.savez(sys.argv[1], *out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    outs = {}
+    for name in ("all_on", "EIOKU_STEM_CHAIN", "EIOKU_STEM_FUSE", "EIOKU_CLSMAX", "EIOKU_LAZY_BOX"):
+        path = tmp_path / f"dets_{name}.npz"
+        env = dict(os.environ) if name == "all_on" else dict(os.environ, **{name: "0"})
+        subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=env, timeout=300)
+        with np.load(path) as z:
+            outs[name] = [z[k] for k in z.files]
+    assert sum(int(a.size) for a in outs["all_on"]) > 15 * 32
+    for name, got in outs.items():
+        assert len(got) == len(outs["all_on"]), name
+        for a, b in zip(got, outs["all_on"]):
+            assert np.array_equal(a, b), name
+
+
 @pytest.mark.parametrize("h,w", [(470, 640), (640, 470), (640, 472), (940, 1280), (1280, 940), (96, 160)])
 def test_fused_stem_equals_letterbox_then_network(gpu, h, w):
     """detect() lets the stem read the BGR frames itself in the copy / exact-half letterbox modes (the fp16
