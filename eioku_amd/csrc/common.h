@@ -74,4 +74,17 @@ __device__ __forceinline__ T wave_reduce_add(T v) {
   return v;
 }
 
+// Sum of a 32-bit value over the wave on the DPP crossbar: six v_add_u32_dpp and one v_readlane_b32, against ~25
+// instructions (ds_bpermute + address + bounds select per step) for the __shfl_down form -- the per-frame reductions
+// of the VALU-bound scene kernels.  The result is wave-uniform (an SGPR).
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror: every lane = its row's sum
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);  // row_bcast:15 into rows 1 and 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);  // row_bcast:31 into rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 }  // namespace eioku

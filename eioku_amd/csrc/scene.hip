@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void k_sad_luma(const uint8_t* __restrict__
       p[u] = cur[u];
       cur[u] = nxt[u];
     }
-    a = wave_reduce_add(a & use);
+    a = wave_sum_u32(a & use);
     if (lane == 0 && a) atomicAdd(&s_acc[t - t_begin], a);
     use = 0xFFFFFFFFu;
   }
@@ -199,18 +199,43 @@ __global__ __launch_bounds__(kBlock) void k_sad_luma_strided(const uint8_t* __re
 // ---------------------------------------------------------------------------------------
 // K2: BGR -> HSV (OpenCV RGB2HSV_b, hrange 180) + per-channel SAD against the previous frame
 // ---------------------------------------------------------------------------------------
+// 24-bit multiply-adds spelled out: left to the compiler, __mul24 of operands whose range it can see became a
+// quarter-rate v_mul_lo_u32 (20 of the 32 multiplies per 16 pixels)
+__device__ __forceinline__ int mad_u24(int a, int b, int c) {
+  int d;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int mad_i24(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int max3_u(int a, int b, int c) {
+  int d;
+  asm("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int min3_u(int a, int b, int c) {
+  int d;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 __device__ __forceinline__ void hsv_px(int b, int g, int r, const int* __restrict__ sdiv,
                                        const int* __restrict__ hdiv, int& H, int& S, int& V) {
-  int v = max(max(b, g), r);
-  int vmin = min(min(b, g), r);
-  int diff = v - vmin;
-  int s = (__mul24(diff, sdiv[v]) + 2048) >> 12;
-  // masks, as in OpenCV's own source: ternaries here were compiled to a divergent branch per pixel
-  const int vr = -(int)(v == r), vg = -(int)(v == g);
-  int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + (~vg & (r - g + 4 * diff))));
-  h = (__mul24(h, hdiv[diff]) + 2048) >> 12;  // arithmetic shift: floor, as in the C source
-  h += (h >> 31) & 180;
-  H = h;
+  const int v = max3_u(b, g, r);
+  const int vmin = min3_u(b, g, r);
+  const int diff = v - vmin;
+  const int s = mad_u24(diff, sdiv[v], 2048) >> 12;
+  // OpenCV's mask arithmetic, (vr & (g - b)) + (~vr & ((vg & (b - r + 2 diff)) + (~vg & (r - g + 4 diff)))), as two
+  // selects over values that are all computed first (nothing for the compiler to branch around)
+  const int hr = g - b, hg = b - r + 2 * diff, hb = r - g + 4 * diff;
+  const int hsel = v == g ? hg : hb;
+  int h = v == r ? hr : hsel;
+  h = mad_i24(h, hdiv[diff], 2048) >> 12;  // arithmetic shift: floor, as in the C source
+  // h in [-90, 180]: "h += 180 if h < 0" as an unsigned minimum (a negative h is a huge unsigned number)
+  H = (int)min((unsigned)h, (unsigned)(h + 180));
   S = s;
   V = v;
 }
@@ -228,6 +253,85 @@ __device__ __forceinline__ void hsv_quad(unsigned d0, unsigned d1, unsigned d2,
   H = (unsigned)h0 | ((unsigned)h1 << 8) | ((unsigned)h2 << 16) | ((unsigned)h3 << 24);
   S = (unsigned)s0 | ((unsigned)s1 << 8) | ((unsigned)s2 << 16) | ((unsigned)s3 << 24);
   V = (unsigned)v0 | ((unsigned)v1 << 8) | ((unsigned)v2 << 16) | ((unsigned)v3 << 24);
+}
+
+// The same conversion on 16-bit pairs (VOP3P): two pixels per instruction for everything up to the hue numerator,
+// one 24-bit multiply-add per pixel and channel, byte permutes instead of shifts.  k_hsv_sums is VALU-issue bound
+// (PMC: SQ_ACTIVE_INST_VALU = 99 % of the kernel's cycles at 35 instructions per pixel); this form needs ~21.
+//   * sdiv4[v] = 4 sdiv[v], hdiv16[d] = 16 hdiv[d], the multiplicand of S is 4 diff: both products come out scaled
+//     by 16, so that (x + 2048) >> 12 is the byte / half-word at bit 16 of (16 x + 32768): no shift instructions;
+//   * v == r / v == g as sign masks of r - v, g - v (both <= 0), the two selects as v_bfi_b32 on the pair;
+//   * "h += 180 if h < 0" as an unsigned 16-bit minimum of h and h + 180.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+template <int W>
+__device__ __forceinline__ unsigned word_shl2(unsigned a) {  // 4 * (16-bit half W of a)
+  unsigned d;
+  if (W == 0) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d) : "v"(a));
+  else asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d) : "v"(a));
+  return d;
+}
+template <int K>
+__device__ __forceinline__ unsigned pk_mad_i16(unsigned a, unsigned c) {  // a * K + c on both halves
+  unsigned d;
+  asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "n"(K), "v"(c));
+  return d;
+}
+__device__ __forceinline__ unsigned pk_sign_i16(unsigned a) {  // 0xffff in every half that is negative
+  unsigned d;
+  asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(a));
+  return d;
+}
+__device__ __forceinline__ unsigned bfi(unsigned mask, unsigned x, unsigned y) {  // (mask & x) | (~mask & y)
+  unsigned d;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(x), "v"(y));
+  return d;
+}
+
+__device__ __forceinline__ void hsv_pair(unsigned B, unsigned G, unsigned R, const int* __restrict__ sdiv4,
+                                         const int* __restrict__ hdiv16, unsigned& Hp, int& s0, int& s1, unsigned& Vp) {
+  const u16x2 b = __builtin_bit_cast(u16x2, B), g = __builtin_bit_cast(u16x2, G), r = __builtin_bit_cast(u16x2, R);
+  const u16x2 v = __builtin_elementwise_max(__builtin_elementwise_max(b, g), r);
+  const u16x2 vmin = __builtin_elementwise_min(__builtin_elementwise_min(b, g), r);
+  const u16x2 diff = v - vmin;
+  const s16x2 bs = __builtin_bit_cast(s16x2, b), gs = __builtin_bit_cast(s16x2, g), rs = __builtin_bit_cast(s16x2, r);
+  const s16x2 vs = __builtin_bit_cast(s16x2, v), ds = __builtin_bit_cast(s16x2, diff);
+  // (spelled out: the compiler turned the sign masks into per-half compares + selects + a re-pack)
+  const unsigned hr = __builtin_bit_cast(unsigned, gs - bs);
+  const unsigned hg = pk_mad_i16<2>(__builtin_bit_cast(unsigned, ds), __builtin_bit_cast(unsigned, bs - rs));
+  const unsigned hb = pk_mad_i16<4>(__builtin_bit_cast(unsigned, ds), __builtin_bit_cast(unsigned, rs - gs));
+  const unsigned nr = pk_sign_i16(__builtin_bit_cast(unsigned, rs - vs));  // all ones where v != r
+  const unsigned ng = pk_sign_i16(__builtin_bit_cast(unsigned, gs - vs));
+  const int hn = (int)bfi(nr, bfi(ng, hb, hg), hr);
+  // table byte offsets 4 v, 4 diff of the two pixels: shift and half-word select in one SDWA instruction each
+  const unsigned v4a = word_shl2<0>(__builtin_bit_cast(unsigned, v)), v4b = word_shl2<1>(__builtin_bit_cast(unsigned, v));
+  const unsigned d4a = word_shl2<0>(__builtin_bit_cast(unsigned, diff)), d4b = word_shl2<1>(__builtin_bit_cast(unsigned, diff));
+  const char* st = reinterpret_cast<const char*>(sdiv4);
+  const char* ht = reinterpret_cast<const char*>(hdiv16);
+  s0 = mad_u24((int)d4a, *reinterpret_cast<const int*>(st + v4a), 32768);  // S of the pixel = byte 2
+  s1 = mad_u24((int)d4b, *reinterpret_cast<const int*>(st + v4b), 32768);
+  const int h0 = mad_i24((int)(short)(hn & 0xFFFF), *reinterpret_cast<const int*>(ht + d4a), 32768);  // h = high half
+  const int h1 = mad_i24(hn >> 16, *reinterpret_cast<const int*>(ht + d4b), 32768);
+  const u16x2 h = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm((unsigned)h1, (unsigned)h0, 0x07060302u));
+  Hp = __builtin_bit_cast(unsigned, __builtin_elementwise_min(h, (u16x2)(h + (unsigned short)180)));
+  Vp = __builtin_bit_cast(unsigned, v);
+}
+
+__device__ __forceinline__ void hsv_quad_pk(unsigned d0, unsigned d1, unsigned d2, const int* __restrict__ sdiv4,
+                                            const int* __restrict__ hdiv16, unsigned& H, unsigned& S, unsigned& V) {
+  // 12 bytes b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3 -> zero-extended 16-bit pairs (v_perm_b32: selector 0x0c = 0x00;
+  // indices 0-3 = bytes of the second operand, 4-7 = bytes of the first)
+  const unsigned B01 = __builtin_amdgcn_perm(d0, d0, 0x0c030c00u), G01 = __builtin_amdgcn_perm(d1, d0, 0x0c040c01u);
+  const unsigned R01 = __builtin_amdgcn_perm(d1, d0, 0x0c050c02u), B23 = __builtin_amdgcn_perm(d2, d1, 0x0c050c02u);
+  const unsigned G23 = __builtin_amdgcn_perm(d2, d1, 0x0c060c03u), R23 = __builtin_amdgcn_perm(d2, d2, 0x0c030c00u);
+  unsigned H01, H23, V01, V23;
+  int s0, s1, s2, s3;
+  hsv_pair(B01, G01, R01, sdiv4, hdiv16, H01, s0, s1, V01);
+  hsv_pair(B23, G23, R23, sdiv4, hdiv16, H23, s2, s3, V23);
+  H = __builtin_amdgcn_perm(H23, H01, 0x06040200u);
+  V = __builtin_amdgcn_perm(V23, V01, 0x06040200u);
+  S = __builtin_amdgcn_perm((unsigned)s1, (unsigned)s0, 0x0c0c0602u) | __builtin_amdgcn_perm((unsigned)s3, (unsigned)s2, 0x06020c0cu);
 }
 
 struct Quad3 {
@@ -263,8 +367,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_hsv_sums(const uint8_t* __restric
   __shared__ int s_hdiv[256];
   __shared__ unsigned s_acc[kMaxSeg * 3];
   const int tid = threadIdx.x, lane = tid & 63;
-  s_sdiv[tid] = c_sdiv[tid];
-  s_hdiv[tid] = c_hdiv[tid];
+  s_sdiv[tid] = 4 * c_sdiv[tid];   // pre-scaled for hsv_quad_pk
+  s_hdiv[tid] = 16 * c_hdiv[tid];
   if (tid < kMaxSeg * 3) s_acc[tid] = 0;
   __syncthreads();
 
@@ -292,41 +396,44 @@ __global__ __launch_bounds__(kBlock, 4) void k_hsv_sums(const uint8_t* __restric
     pH[u] = pS[u] = pV[u] = 0;
     if (pf) {
       Quad3 d = load_quad<ALIGNED>(pf, q[u]);
-      hsv_quad(d.d0, d.d1, d.d2, s_sdiv, s_hdiv, pH[u], pS[u], pV[u]);
+      hsv_quad_pk(d.d0, d.d1, d.d2, s_sdiv, s_hdiv, pH[u], pS[u], pV[u]);
       pH[u] &= mask[u];
       pS[u] &= mask[u];
       pV[u] &= mask[u];
     }
     cur[u] = load_quad<ALIGNED>(frames + (size_t)t_begin * frame_stride, q[u]);
   }
-#pragma unroll 1
-  for (int t = t_begin; t < t_end; ++t) {
-    Quad3 nxt[Q];
+  // One frame: the next one is requested first (registers `nx`), then `c` is converted and compared with the previous
+  // frame's H / S / V.  Two steps per trip with the register sets swapped, so that no frame is ever copied; only the
+  // workgroup that holds the end of the frame pays for the lane masks (MASKED is workgroup-uniform).
+  auto step = [&](int t, Quad3 (&c)[Q], Quad3 (&nx)[Q], auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     {
       const int tn = t + 1 < t_end ? t + 1 : t;
       const uint8_t* f = frames + (size_t)tn * frame_stride;
 #pragma unroll
-      for (int u = 0; u < Q; ++u) nxt[u] = load_quad<ALIGNED>(f, q[u]);
+      for (int u = 0; u < Q; ++u) nx[u] = load_quad<ALIGNED>(f, q[u]);
     }
     unsigned aH = 0, aS = 0, aV = 0;
 #pragma unroll
     for (int u = 0; u < Q; ++u) {
       unsigned H, S, V;
-      hsv_quad(cur[u].d0, cur[u].d1, cur[u].d2, s_sdiv, s_hdiv, H, S, V);
-      H &= mask[u];
-      S &= mask[u];
-      V &= mask[u];
+      hsv_quad_pk(c[u].d0, c[u].d1, c[u].d2, s_sdiv, s_hdiv, H, S, V);
+      if (MASKED) {
+        H &= mask[u];
+        S &= mask[u];
+        V &= mask[u];
+      }
       aH = __builtin_amdgcn_sad_u8(H, pH[u], aH);
       aS = __builtin_amdgcn_sad_u8(S, pS[u], aS);
       aV = __builtin_amdgcn_sad_u8(V, pV[u], aV);
       pH[u] = H;
       pS[u] = S;
       pV[u] = V;
-      cur[u] = nxt[u];
     }
-    aH = wave_reduce_add(aH & use);
-    aS = wave_reduce_add(aS & use);
-    aV = wave_reduce_add(aV & use);
+    aH = wave_sum_u32(aH & use);
+    aS = wave_sum_u32(aS & use);
+    aV = wave_sum_u32(aV & use);
     if (lane == 0) {
       unsigned* a = s_acc + (t - t_begin) * 3;
       if (aH) atomicAdd(a, aH);
@@ -334,7 +441,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_hsv_sums(const uint8_t* __restric
       if (aV) atomicAdd(a + 2, aV);
     }
     use = 0xFFFFFFFFu;
-  }
+  };
+  auto run = [&](auto masked_tag) {
+    Quad3 alt[Q];
+    int t = t_begin;
+#pragma unroll 1
+    for (; t + 1 < t_end; t += 2) {
+      step(t, cur, alt, masked_tag);
+      step(t + 1, alt, cur, masked_tag);
+    }
+    if (t < t_end) step(t, cur, alt, masked_tag);
+  };
+  if (((unsigned long long)blockIdx.x + 1) * Q * kBlock > nquads) run(std::true_type{});
+  else run(std::false_type{});
   flush_run<3>(s_acc, t_begin, t_end, sums);
 }
 
@@ -402,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void k_sad_luma_bgr(const uint8_t* __restri
       pY[u] = Y;
       cur[u] = nxt[u];
     }
-    a = wave_reduce_add(a & use);
+    a = wave_sum_u32(a & use);
     if (lane == 0 && a) atomicAdd(&s_acc[t - t_begin], a);
     use = 0xFFFFFFFFu;
   }
@@ -463,8 +582,11 @@ __global__ __launch_bounds__(kBlock) void k_bgr2hsv(const uint8_t* __restrict__ 
 
 // Split n frames into runs of `seg` (multiple of kG) so the grid has >= ~8 workgroups per CU
 // when the frame is small, while keeping the one-extra-frame-per-run overhead low.
-int pick_seg(int n, unsigned long long blocks_x) {
-  const unsigned long long want = (unsigned long long)num_cus() * 8;
+// per_cu: workgroups the launch should offer every CU.  Every run converts (K2) or reads (K1) the frame before its
+// first one again, so shorter runs cost 1 / seg extra work: K2, VALU-bound with 5 resident workgroups per CU, is 3 %
+// faster at 1080p with runs of 16 (per_cu = 5) than with runs of 8 (per_cu = 8); measured 100.9 vs 104.1 us.
+int pick_seg(int n, unsigned long long blocks_x, int per_cu = 8) {
+  const unsigned long long want = (unsigned long long)num_cus() * per_cu;
   int seg = ((n + kG - 1) / kG) * kG;  // one run
   if (seg > kMaxSeg) seg = kMaxSeg;     // the run's sums live in LDS
   while (seg > kG && blocks_x * (unsigned long long)((n + seg - 1) / seg) < want) {
@@ -588,7 +710,7 @@ int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t 
   unsigned long long nquads = npix >> 2;
   unsigned long long bx = (nquads + (unsigned long long)kBlock * Q - 1) / ((unsigned long long)kBlock * Q);
   if (bx == 0) bx = 1;
-  int seg = pick_seg(n, bx);
+  int seg = pick_seg(n, bx, 5);
   dim3 grid((unsigned)bx, (unsigned)((n + seg - 1) / seg));
   const bool aligned = (((uintptr_t)d_frames | frame_stride | (d_prev ? (uintptr_t)d_prev : 0)) & 3) == 0;
   if (nquads) {
