@@ -80,6 +80,12 @@ SIGNATURES = {
     "eioku_index_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong]),
     "eioku_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "eioku_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "eioku_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "eioku_comm_destroy": (None, [C.c_void_p]),
+    "eioku_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "eioku_index_search_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "eioku_bert_create": (C.c_int, [C.c_int] * 7 + [C.c_float, C.POINTER(C.c_void_p)]),
     "eioku_bert_destroy": (None, [C.c_void_p]),
     "eioku_bert_num_tensors": (C.c_int, [C.c_void_p]),

@@ -208,3 +208,66 @@ class ShardedFlatL2:
         dl = gathered[:, :, :k].to(torch.int32).view(torch.float32).contiguous()
         il = gathered[:, :, k:].contiguous()
         return self.merge(dl, il, k)
+
+
+class RcclComm:
+    """The library's own RCCL communicator (``eioku_comm_*``): for hosts that hold no ``torch.distributed`` process
+    group.  Rank 0 calls :meth:`unique_id` and ships the 128 bytes to its peers by whatever channel the service has;
+    every rank (one process per GPU) then constructs ``RcclComm(id, rank, world)`` -- a collective call."""
+
+    ID_BYTES = 128
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        import ctypes as C
+
+        if len(unique_id) != self.ID_BYTES:
+            raise ValueError(f"unique id must be {self.ID_BYTES} bytes, got {len(unique_id)}")
+        self._lib = _lib.load()
+        _lib.init()
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), self.ID_BYTES)
+        _lib.check(self._lib.eioku_comm_create(C.cast(buf, C.c_void_p), int(rank), int(world), C.byref(h)), "eioku_comm_create")
+        self._h, self.rank, self.world = h, int(rank), int(world)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        lib = _lib.load()
+        buf = C.create_string_buffer(RcclComm.ID_BYTES)
+        _lib.check(lib.eioku_comm_unique_id(C.cast(buf, C.c_void_p)), "eioku_comm_unique_id")
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.eioku_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CommShardedFlatL2:
+    """:class:`ShardedFlatL2` with the collective inside the C ABI (``eioku_index_search_sharded``): local shard
+    search, one RCCL all-gather of the packed answers, local merge.  ``local`` is this rank's :class:`IndexFlatL2`."""
+
+    def __init__(self, local: "IndexFlatL2", id_base: int, comm: RcclComm):
+        self.local, self.id_base, self.comm = local, int(id_base), comm
+
+    def search(self, q, k: int):
+        import torch
+
+        if not on_device(q):
+            raise _lib.EiokuHipError("eioku_index_search_sharded takes device queries")
+        nq, d = (int(s) for s in q.shape)
+        if d != self.local.d:
+            raise ValueError(f"expected dimension {self.local.d}, got {d}")
+        q = q.contiguous()
+        D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        _lib.check(self.local._lib.eioku_index_search_sharded(self.local._h, self.comm._h, self.id_base, ptr(q), nq, int(k),
+                                                              ptr(D), ptr(I), current_stream(q)), "eioku_index_search_sharded")
+        return D, I

@@ -230,6 +230,24 @@ int eioku_index_set_param(eioku_index_t* ix, const char* name, long long value);
 int eioku_topk_merge(const float* d_lists, const int64_t* i_lists, int nlists, int nq, int k, float* D,
                      int64_t* I, void* stream);
 
+/* ---- C1 without a torch process group: sharded exact search over RCCL ----------------------------------
+ * The reference holds intent only (.kiro/specs/semantic-video-search/design.md:58-61: one FAISS index per node);
+ * BASELINE.json's north_star asks for "per-GPU FAISS-style shards ... merged via a single RCCL all-gather" behind
+ * the C ABI.  Rank 0 makes an id (eioku_comm_unique_id) and ships the 128 bytes to its peers out of band (the
+ * service's own RPC, a file, MPI ...); every rank, one process per GPU, then calls eioku_comm_create -- a
+ * collective, like ncclCommInitRank, which it wraps -- and from then on eioku_index_search_sharded with the same
+ * nq and k: local shard search, ONE all-gather of nq*k*12 bytes per rank over xGMI, local merge.  Every rank
+ * receives the same global answer.  q / D / I are DEVICE pointers; ids are id_base + the shard's local row.
+ * RCCL is bound with dlopen at first use (EIOKU_ENODEV if librccl.so is absent). */
+#define EIOKU_COMM_ID_BYTES 128
+typedef struct eioku_comm eioku_comm_t;
+int eioku_comm_unique_id(unsigned char* id128);
+int eioku_comm_create(const unsigned char* id128, int rank, int world, eioku_comm_t** out);
+void eioku_comm_destroy(eioku_comm_t* comm);
+int eioku_comm_rank(const eioku_comm_t* comm, int* rank, int* world);
+int eioku_index_search_sharded(eioku_index_t* ix, eioku_comm_t* comm, long long id_base, const float* q, int nq,
+                               int k, float* D, int64_t* I, void* stream);
+
 /* ---- segment embedding: all-MiniLM-L6-v2 (BERT encoder + mean pooling + L2 norm) ----------
  * The reference holds intent only (.kiro/specs/semantic-video-search/design.md:54-57,1096-1103;
  * tasks.md:297-302 unchecked); BASELINE.json's north_star names all-MiniLM-L6-v2: vocab 30522,
