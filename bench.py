@@ -391,6 +391,7 @@ def main():
                        "batch": args.batch, "frame": [height, width], "parallelism": f"shard-by-video x{world}"},
             "roofline": {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": achieved, "peak": dom["peak"],
                          "unit": dom["unit"], "frac": achieved / dom["peak"], "traffic": traffic, "traffic_note": tnote,
+                         "traffic_per_launch": (traffic / dom["launches"] * max(pipe.prof_steps, 1)) if traffic else None,
                          "avg_kernel_ms": avg_ms, "launches": dom["launches"],
                          "kernel_ms_per_step": dom["ms_total"] / max(pipe.prof_steps, 1), "profiled_steps": pipe.prof_steps,
                          "algorithmic_per_step": dom["alg_per_step"], "scene_kernels": pipe.scene_kernels()},
