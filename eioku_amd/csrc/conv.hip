@@ -1647,6 +1647,19 @@ int launch_c8_dispatch(int nf, int src, const ConvArgs& a, const FusedSrc& fs, i
   return EIOKU_OK;
 }
 
+// Workgroups of `kernel` that can be RESIDENT on one CU, registers included: a persistent grid sized from LDS alone
+// runs its surplus workgroups as a second, half-empty round (k_conv3x3_chain<1,...,1,2>: 174 VGPRs = two waves per
+// SIMD = two workgroups per CU, launched three per CU because three fit its LDS).
+template <typename K>
+int resident_per_cu(K kernel, int threads, size_t lds) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) {
+    (void)hipGetLastError();
+    n = 1;
+  }
+  return n;
+}
+
 template <int NF, int S, int NCH, bool DB, bool POST = false, int NWV = 4>
 int launch_persist(const ConvArgs& a_in, int ntiles, hipStream_t stream) {
   constexpr int TH = 2 * NWV;
@@ -1667,6 +1680,8 @@ int launch_persist(const ConvArgs& a_in, int ntiles, hipStream_t stream) {
   int per_cu = (int)((size_t)160 * 1024 / lds);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
+  static const int occ = resident_per_cu(k_conv3x3_persist<NF, S, NCH, DB, POST, NWV>, 64 * NWV, lds);
+  if (per_cu > occ) per_cu = occ;
   int bx = num_cus() * per_cu / ntiles;
   if (bx < 1) bx = 1;
   if (bx > total) bx = total;
@@ -1737,6 +1752,8 @@ int launch_chain(const ConvArgs& a, const ChainCat& cc, hipStream_t stream) {
   int per_cu = (int)(160 * 1024 / lds);  // two 80.3 KB workgroups (32-channel C2f + its closing 1x1) share a CU
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
+  static const int occ = resident_per_cu(k_conv3x3_chain<NF, DB, CAT, NF2>, 256, lds);
+  if (per_cu > occ) per_cu = occ;
   int bx = num_cus() * per_cu;
   if (bx > total) bx = total;
   hipLaunchKernelGGL((k_conv3x3_chain<NF, DB, CAT, NF2>), dim3((unsigned)bx), dim3(256), lds, stream, a, cc, total);

@@ -676,7 +676,8 @@ struct ScanArgs {
   const float* qnorm;    // [nq]
   const float* tau;      // sample search result [nq][tau_k]; the bound is its last column
   int tau_k;
-  long long n, ntiles;
+  long long n, ntiles;   // ntiles: row tiles THIS launch visits; tile t is physical tile t * tstride
+  long long tstride;     // 1: every tile; > 1: the strided subset that tightens the bound first (scan_search)
   int nq, nqt;
   // candidates leave the scan as (query, row) pairs in a list private to the workgroup (an LDS counter hands out the
   // slots: no global atomic, nothing to wait for); k_scan_bin sorts them into the per-query lists afterwards
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(NW * 64) void k_l2_scan(ScanArgs a) {
   long long wt = blockIdx.x;
   auto tile_of = [&](long long w, int i) {
     const long long t = (w * NW + wave) * RT + i;
-    return t < a.ntiles ? t : a.ntiles - 1;  // clamped duplicates are masked through `own` below
+    return (t < a.ntiles ? t : a.ntiles - 1) * a.tstride;  // clamped duplicates are masked through `own` below
   };
   // lanes 0..31 each read one row's half norm; the hot loop only needs the tile's minimum, the per-row values wait in
   // LDS for the rare tile that may hold a candidate (16 registers less in the loop)
@@ -844,6 +845,8 @@ __global__ __launch_bounds__(NW * 64) void k_l2_scan(ScanArgs a) {
       for (int i = 0; i < RT; ++i) {
         const f32x16& c = acc[i];
         const float thr_q = hcq - sqq * sxm[i];
+        // (fmaxf costs a canonicalising v_max_f32 x, x per accumulator; v_max3_f32 in inline asm does not, but the
+        // compiler's hazard recogniser does not see an asm's read of a just-written MFMA result: wrong values, reverted)
         float m01 = fmaxf(fmaxf(c[0], c[1]), c[2]), m23 = fmaxf(fmaxf(c[3], c[4]), c[5]);
         float m45 = fmaxf(fmaxf(c[6], c[7]), c[8]), m67 = fmaxf(fmaxf(c[9], c[10]), c[11]);
         float m89 = fmaxf(fmaxf(c[12], c[13]), c[14]);
@@ -1030,6 +1033,8 @@ struct eioku_index {
   int* wl_cnt = nullptr; size_t wlccap = 0;
   float* tau = nullptr; size_t taucap = 0;
   long long* tau_i = nullptr; size_t tauicap = 0;
+  float* tau1 = nullptr; size_t tau1cap = 0;       // the strided pre-scan's exact top-k (its last column tightens tau)
+  long long* tau1_i = nullptr; size_t tau1icap = 0;
   int* cand_i = nullptr; size_t cicap = 0;
   int* cnt = nullptr; size_t cntcap = 0;  // [nq] counters + 1 overflow word
   // parameters (eioku_index_set_param)
@@ -1037,6 +1042,7 @@ struct eioku_index {
   int scan_cap = 4096;         // candidate slots per query
   long long scan_min_rows = 262144;
   long long scan_sample = 0;   // sample rows for the bound (0: automatic)
+  int scan_prescan = 32;       // stride of the pre-scan's row tiles (0: no pre-scan, the sample alone bounds the scan)
   int scan_rt = 2;             // row tiles per wave: 2 (8 waves per workgroup; 2-3 % faster at 10 M x 384) or 1 (12 waves)
 };
 
@@ -1114,7 +1120,7 @@ void eioku_index_destroy(eioku_index* ix) {
   (void)hipDeviceSynchronize();
   if (ix->x && !ix->attached) (void)hipFree(ix->x);
   void* bufs[] = {ix->norms, ix->qbuf, ix->qnorm, ix->pd, ix->pi, ix->dout, ix->iout, ix->xh, ix->hnorm,
-                  ix->tmax, ix->qh, ix->wl, ix->wl_cnt, ix->tau, ix->tau_i, ix->cand_i, ix->cnt};
+                  ix->tmax, ix->qh, ix->wl, ix->wl_cnt, ix->tau, ix->tau_i, ix->tau1, ix->tau1_i, ix->cand_i, ix->cnt};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete ix;
@@ -1341,6 +1347,14 @@ int ensure_planes(eioku_index* ix, hipStream_t stream) {
   return EIOKU_OK;
 }
 
+// the bound of query q = the smaller of two valid ones (the k-th best of ANY k rows bounds the k-th best of all)
+__global__ void k_tau_min(float* __restrict__ tau, const float* __restrict__ other, int nq, int k) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const size_t j = (size_t)q * k + (k - 1);
+  tau[j] = fminf(tau[j], other[j]);
+}
+
 template <int D>
 int launch_scan(eioku_index* ix, ScanArgs& a, int rt, long long* grid_out, hipStream_t stream) {
   constexpr int PU = (D / 16) * 64;
@@ -1405,9 +1419,18 @@ int scan_search(eioku_index* ix, const float* dq, int nq, int k, float* dD, long
   EIOKU_HIP_CHECK(hipMemsetAsync(ix->cnt, 0, ((size_t)nq + 1) * sizeof(int), stream));
   rc = split_planes(d, dq, nq, 0, nqt, nullptr, ix->qh, nullptr, nullptr, true, stream);
   if (rc) return rc;
-  // bound: exact search of a strided sample (k-th best of a subset >= k-th best of the whole): N / 128 rows, in
-  // slabs long enough to amortise each workgroup's 128-query operand load
-  long long sample = ix->scan_sample > 0 ? ix->scan_sample : ix->n / 128;
+  // Bound, in two steps (the k-th best of ANY subset of the rows bounds the k-th best of all of them):
+  //  1. exact register-tile search of a strided sample of N / sample_div rows, in slabs long enough to amortise each
+  //     workgroup's 128-query operand load;
+  //  2. (pre-scan) THIS scan path over every `stride`-th row tile with the bound of step 1, its candidates re-ranked
+  //     exactly: the k-th best of N / stride rows.  With the sample alone (N / 128 rows) a query keeps ~128 k
+  //     candidates in the full scan - 1.3 M list entries to bin and 1.2 GB of rows to gather and re-rank per 1024
+  //     queries at 10 M rows (0.9 ms) on top of the sample search (0.9 ms); with a 512th sampled and a 32nd pre-scanned
+  //     the three small steps cost about as much as one of those.
+  const long long ntiles_all = (ix->n + 31) / 32;
+  int stride = ix->scan_prescan;
+  if (stride > 0 && ntiles_all / stride < 64) stride = 0;  // too few rows for a meaningful second bound
+  long long sample = ix->scan_sample > 0 ? ix->scan_sample : ix->n / (stride ? 512 : 128);
   if (sample < 32768) sample = 32768;
   if (sample > 262144) sample = 262144;
   // exactly one round of workgroups on the chip: (query groups of 128) x slabs <= CUs - every workgroup of that kernel
@@ -1429,26 +1452,45 @@ int scan_search(eioku_index* ix, const float* dq, int nq, int k, float* dD, long
   a.tau = ix->tau;
   a.tau_k = k;
   a.n = ix->n;
-  a.ntiles = (ix->n + 31) / 32;
   a.nq = nq;
   a.nqt = nqt;
   long long sgrid = 0;
-  prof_start(EIOKU_PROF_KNN, stream);
-  switch (d) {
-    case 128: rc = launch_scan<128>(ix, a, ix->scan_rt, &sgrid, stream); break;
-    case 256: rc = launch_scan<256>(ix, a, ix->scan_rt, &sgrid, stream); break;
-    default: rc = launch_scan<384>(ix, a, ix->scan_rt, &sgrid, stream); break;
+  auto scan_bin_select = [&](long long ntiles, long long tstride, float* outD, long long* outI, int* oflow, bool prof) -> int {
+    a.ntiles = ntiles;
+    a.tstride = tstride;
+    if (prof) prof_start(EIOKU_PROF_KNN, stream);
+    int r;
+    switch (d) {
+      case 128: r = launch_scan<128>(ix, a, ix->scan_rt, &sgrid, stream); break;
+      case 256: r = launch_scan<256>(ix, a, ix->scan_rt, &sgrid, stream); break;
+      default: r = launch_scan<384>(ix, a, ix->scan_rt, &sgrid, stream); break;
+    }
+    if (prof) prof_stop(EIOKU_PROF_KNN, stream);
+    if (r) return r;
+    hipLaunchKernelGGL(k_scan_bin, dim3((unsigned)sgrid), dim3(256), 0, stream, ix->wl, ix->wl_cnt, a.wl_cap, ix->cand_i,
+                       ix->cnt, cap, oflow);
+    EIOKU_LAUNCH_CHECK();
+    switch (d) {
+      case 128: return launch_select<128>(ix, dq, nq, cap, k, outD, outI, oflow, stream);
+      case 256: return launch_select<256>(ix, dq, nq, cap, k, outD, outI, oflow, stream);
+      default: return launch_select<384>(ix, dq, nq, cap, k, outD, outI, oflow, stream);
+    }
+  };
+  if (stride > 0) {
+    rc = grow(&ix->tau1, &ix->tau1cap, (size_t)nq * k * sizeof(float));
+    if (rc) return rc;
+    rc = grow(&ix->tau1_i, &ix->tau1icap, (size_t)nq * k * sizeof(long long));
+    if (rc) return rc;
+    // a pre-scan list that overflows is merely truncated: the k best of the entries that did fit are k real rows, so
+    // their k-th distance is still a valid bound (fewer than k entries: FLT_MAX, and the sample's bound stands).  Its
+    // overflow word is the one the memset below clears again.
+    rc = scan_bin_select((ntiles_all + stride - 1) / stride, stride, ix->tau1, ix->tau1_i, overflow, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tau_min, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, ix->tau, ix->tau1, nq, k);
+    EIOKU_LAUNCH_CHECK();
+    EIOKU_HIP_CHECK(hipMemsetAsync(ix->cnt, 0, ((size_t)nq + 1) * sizeof(int), stream));
   }
-  prof_stop(EIOKU_PROF_KNN, stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_scan_bin, dim3((unsigned)sgrid), dim3(256), 0, stream, ix->wl, ix->wl_cnt, a.wl_cap, ix->cand_i, ix->cnt,
-                     cap, overflow);
-  EIOKU_LAUNCH_CHECK();
-  switch (d) {
-    case 128: rc = launch_select<128>(ix, dq, nq, cap, k, dD, dI, overflow, stream); break;
-    case 256: rc = launch_select<256>(ix, dq, nq, cap, k, dD, dI, overflow, stream); break;
-    default: rc = launch_select<384>(ix, dq, nq, cap, k, dD, dI, overflow, stream); break;
-  }
+  rc = scan_bin_select(ntiles_all, 1, dD, dI, overflow, true);
   if (rc) return rc;
   // a list overflowed (adversarial data for the sample bound): the gated register-tile search redoes the group
   return legacy_search(ix, dq, nq, k, nullptr, nullptr, dD, dI, overflow, 0, 0, false, stream);
@@ -1555,6 +1597,9 @@ int eioku_index_set_param(eioku_index* ix, const char* name, long long value) {
   } else if (!strcmp(name, "scan_sample")) {
     EIOKU_REQUIRE(value >= 0, "scan_sample must be >= 0");
     ix->scan_sample = value;
+  } else if (!strcmp(name, "scan_prescan")) {
+    EIOKU_REQUIRE(value == 0 || (value >= 2 && value <= 1024), "scan_prescan is 0 (off) or a tile stride in [2, 1024]");
+    ix->scan_prescan = (int)value;
   } else if (!strcmp(name, "scan_rt")) {
     EIOKU_REQUIRE(value == 1 || value == 2, "scan_rt must be 1 or 2");
     ix->scan_rt = (int)value;

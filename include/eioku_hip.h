@@ -222,7 +222,8 @@ int eioku_index_search_after(eioku_index_t* ix, const float* q, int nq, int k, c
 /* Tuning / test knobs of the wide-search ("scan") path, see csrc/knn.hip: "scan_mode" 0 = register-tile kernels only,
  * 1 (default) = searches with nq > 64 over >= "scan_min_rows" rows keep row tiles stationary, filter with one bf16
  * product term and re-rank the candidates in fp32; "scan_cap" candidate slots per query (a list that overflows falls
- * back to the register-tile kernels); "scan_sample" rows of the bounding sample (0 = automatic); "scan_rt" 1 or 2
+ * back to the register-tile kernels); "scan_sample" rows of the bounding sample (0 = automatic); "scan_prescan" stride of the row tiles the
+ * scan visits FIRST to tighten that bound (default 32; 0 = off, the sample alone bounds the scan); "scan_rt" 1 or 2
  * row tiles per wave (12 / 8 waves per workgroup). */
 int eioku_index_set_param(eioku_index_t* ix, const char* name, long long value);
 /* C1 helper: merge nlists per-shard results [nlists][nq][k] (ids already global) -> [nq][k].

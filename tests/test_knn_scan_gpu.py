@@ -49,6 +49,26 @@ def test_scan_matches_float64_truth(gpu, n, nq, k, d, rt):
     ix.close()
 
 
+@pytest.mark.parametrize("n,nq,k,d,rt,stride", [(20000, 70, 10, 384, 2, 4), (50001, 300, 10, 384, 1, 8), (33333, 200, 16, 256, 2, 2),
+                                                (40000, 129, 10, 128, 2, 4), (9000, 40, 3, 384, 2, 0)])
+def test_prescan_bound_keeps_the_answer_exact(gpu, n, nq, k, d, rt, stride):
+    """The bound is tightened by scanning every `stride`-th row tile first (k-th best of that subset) before the full
+    scan; small strides so that small databases have a meaningful subset (the default, 32, needs >= 64 sampled tiles
+    and is exercised by the 10 M case); 0 = the sample alone.  A tiny candidate cap truncates the pre-scan's lists:
+    still a valid bound, still the exact answer."""
+    xb = unit_rows(33, n, d)
+    for cap in (4096, 64):
+        xq = unit_rows(34, nq, d)
+        if cap == 4096:  # (a final list that overflows goes to the register-tile kernels, whose |q|^2 + |x|^2 - 2 q.x
+            xq[:3] = xb[[7, n // 3, n - 2]] + 0.002 * xq[:3]  # carries ~5e-5 absolute on near-zero distances)
+        Dt, It = oknn.search(xb, xq, k)
+        ix = scan_index(d, scan_rt=rt, scan_prescan=stride, scan_cap=cap)
+        ix.add(xb)
+        D, I = ix.search(xq, k)
+        check(D, I, Dt, It, xb, xq)
+        ix.close()
+
+
 def test_scan_agrees_with_register_tile_kernels_and_is_deterministic(gpu):
     import torch
 

@@ -1,5 +1,5 @@
 """kNN over N x 384 on one GPU, every search path side by side (one process, interleaved rounds):
-python tools/knn_bench.py [N] [nq] [mode:rt,...] -> JSON lines (ms per search, scan-kernel ms from HIP events)."""
+python tools/knn_bench.py [N] [nq] [mode:rt[:prescan],...] -> JSON lines (ms per search, scan-kernel ms from HIP events)."""
 import json
 import os
 import sys
@@ -24,9 +24,11 @@ def main():
     ref = None
     results = {}
     for rnd in range(3):
-        for mode, rt in variants:
+        for var in variants:
+            mode, rt = var[0], var[1]
             ix.set_param("scan_mode", mode)
             ix.set_param("scan_rt", rt)
+            ix.set_param("scan_prescan", var[2] if len(var) > 2 else 32)
             D, I = ix.search(q, 10)  # warm (plane, workspaces)
             torch.cuda.synchronize()
             _lib.prof_enable(True, tags=[_lib.PROF_KNN])
@@ -40,10 +42,11 @@ def main():
             ms, cnt = _lib.prof_read(_lib.PROF_KNN)
             if ref is None:
                 ref = I.clone()
-            results.setdefault((mode, rt), []).append((dt * 1e3, ms / max(cnt, 1), float((I == ref).float().mean())))
-    for (mode, rt), r in results.items():
+            results.setdefault(tuple(var), []).append((dt * 1e3, ms / max(cnt, 1), float((I == ref).float().mean())))
+    for var, r in results.items():
+        mode, rt = var[0], var[1]
         best = min(x[0] for x in r)
-        print(json.dumps({"n": n, "nq": nq, "scan_mode": mode, "scan_rt": rt, "ms_per_search_min": best,
+        print(json.dumps({"n": n, "nq": nq, "scan_mode": mode, "scan_rt": rt, "scan_prescan": var[2] if len(var) > 2 else 32, "ms_per_search_min": best,
                           "ms_per_search_all": [round(x[0], 3) for x in r], "main_kernel_ms": [round(x[1], 3) for x in r],
                           "qps": nq / best * 1e3, "ids_equal_to_first_variant": r[0][2],
                           "algorithmic_TFLOPs_on_main_kernel": 2.0 * nq * n * 384 / (min(x[1] for x in r) * 1e-3) / 1e12}), flush=True)
