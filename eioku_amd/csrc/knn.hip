@@ -695,8 +695,9 @@ __global__ __launch_bounds__(NW * 64) void k_l2_scan(ScanArgs a) {
   constexpr int NS = D / 16, PU = NS * 64;  // steps; 16-B units per tile
   constexpr int NDMA = (PU / 64 + NW - 1) / NW;  // LDS-DMA instructions per wave and query tile
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-  u32x4k* qbuf = reinterpret_cast<u32x4k*>(dyn_smem);                      // [2][PU]
-  float* s_hc = reinterpret_cast<float*>(dyn_smem + (size_t)2 * PU * 16);  // [nqt*32] 0.5 (|q|^2 - tau')
+  constexpr int NB = 4;                                                     // query-tile ring: two tiles per barrier
+  u32x4k* qbuf = reinterpret_cast<u32x4k*>(dyn_smem);                      // [NB][PU]
+  float* s_hc = reinterpret_cast<float*>(dyn_smem + (size_t)NB * PU * 16);  // [nqt*32] 0.5 (|q|^2 - tau')
   float* s_sq = s_hc + a.nqt * 32;                                         // [nqt*32] 2^-8-scaled |q|
   float* s_hx = s_sq + a.nqt * 32;                                         // [NW*RT*32] 0.5 |x|^2 of each wave's rows
   int* s_cnt = reinterpret_cast<int*>(s_hx + NW * RT * 32);                // slots handed out in this workgroup's list
@@ -766,10 +767,11 @@ __global__ __launch_bounds__(NW * 64) void k_l2_scan(ScanArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __builtin_amdgcn_sched_barrier(0);
     stage_q(0, 0);
+    if (total > 1) stage_q(1 % a.nqt, 1);
   }
   // Everything below is 32-bit and incremental: a 64-bit `% nqt` per iteration is a ~100-instruction scalar sequence
-  int it = 0;                     // entries consumed so far: entry `it` lives in buffer it & 1
-  int stage_qt = 1 % a.nqt;       // query tile of the next entry to stage
+  int it = 0;                     // entries consumed so far: entry `it` lives in buffer it & (NB - 1)
+  int stage_qt = 2 % a.nqt;       // query tile of the next entry to stage
   for (; wt < nwt; wt += gridDim.x) {
     bool own[RT];
     long long row0[RT], tn[RT];
@@ -783,20 +785,29 @@ __global__ __launch_bounds__(NW * 64) void k_l2_scan(ScanArgs a) {
     }
     for (int qt = 0; qt < a.nqt; ++qt, ++it) {
       const bool last_qt = qt == a.nqt - 1;
-      // Entry `it` has landed (this wave's pieces: vmcnt; everyone's: the barrier) - and so have the operand registers
-      // refilled during the previous iteration - and every wave is done reading the other buffer, which the DMA issued
-      // below overwrites.  A raw s_barrier is not a memory fence to the optimiser (__syncthreads' fence would do, at the
-      // price of its own waits): the empty asm statements keep LDS reads from being hoisted across it, sched_barrier
-      // pins the machine order.
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      // Every second entry the workgroup meets: entries `it` and `it + 1` have landed (this wave's pieces: vmcnt;
+      // everyone's: the barrier) - and so have the operand registers refilled during the previous iteration - and every
+      // wave is done reading the two buffers that the DMAs issued below overwrite.  Between two meetings the waves run
+      // free: one wave's filter and the next tile's first LDS reads overlap another wave's products on the same SIMD
+      // (with a barrier per tile all waves sat in the same phase).  A raw s_barrier is not a memory fence to the
+      // optimiser (__syncthreads' fence would do, at the price of its own waits): the empty asm statements keep LDS reads
+      // from being hoisted across it, sched_barrier pins the machine order.
+      const bool meet = (it & 1) == 0;
+      if (meet || qt == 0) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0); qt == 0: the refilled row operands
+      if (meet) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 2; e < 4; ++e) {
+          if (it + e < total) stage_q(stage_qt, (it + e) & (NB - 1));
+          stage_qt = stage_qt + 1 == a.nqt ? 0 : stage_qt + 1;
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
-      if (it + 1 < total) stage_q(stage_qt, (it + 1) & 1);
-      stage_qt = stage_qt + 1 == a.nqt ? 0 : stage_qt + 1;
-      const u32x4k* qb = qbuf + (size_t)(it & 1) * PU;
+      const u32x4k* qb = qbuf + (size_t)(it & (NB - 1)) * PU;
       const float hcq = s_hc[qt * 32 + col];
       const float sqq = s_sq[qt * 32 + col];
       f32x16 acc[RT];
@@ -1359,7 +1370,7 @@ template <int D>
 int launch_scan(eioku_index* ix, ScanArgs& a, int rt, long long* grid_out, hipStream_t stream) {
   constexpr int PU = (D / 16) * 64;
   const int nw = rt == 2 ? 8 : 12;
-  const size_t lds = (size_t)2 * PU * 16 + (size_t)a.nqt * 32 * 4 * 2 + (size_t)nw * rt * 32 * 4 + 16;
+  const size_t lds = (size_t)4 * PU * 16 + (size_t)a.nqt * 32 * 4 * 2 + (size_t)nw * rt * 32 * 4 + 16;
   const long long nwt = (a.ntiles + (long long)nw * rt - 1) / ((long long)nw * rt);
   // one workgroup per CU: its 12 (8) waves are the three (two) per SIMD that 96 (192) operand registers allow
   long long grid = num_cus();
