@@ -64,10 +64,12 @@ def parse_args():
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the kernel sources: ties a committed PMC traffic measurement to the code it was taken on
-    (the GPU box has no .git, so a commit id cannot be read there)."""
+    """sha256 over the sources of the conv family and of the graph that launches it (conv.hip / yolo.hip / yolo_ops.hip,
+    the headers, the Makefile with its per-file flags): ties a committed PMC traffic measurement of that family to the
+    code it was taken on (the GPU box has no .git, so a commit id cannot be read there)."""
     h = hashlib.sha256()
-    for f in sorted((ROOT / "eioku_amd" / "csrc").glob("*.h*")):
+    csrc = ROOT / "eioku_amd" / "csrc"
+    for f in sorted(list(csrc.glob("*.h")) + [csrc / n for n in ("conv.hip", "yolo.hip", "yolo_ops.hip", "Makefile")]):
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
