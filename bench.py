@@ -231,7 +231,7 @@ def knn_part(args, device, rank, world):
     kernel_s = max(ms * 1e-3 / max(cnt, 1), 1e-9)
     flops = 2.0 * args.knn_nq * rows * d          # 2 * nq * N * d
     one_pass = rows * d * 4                       # the fp32 rows, once
-    scan = args.knn_nq > 64 and rows >= 262144 and mode != 0
+    scan = rows >= 262144 and mode != 0
     out = {"metric": f"kNN QPS@top-10 over {args.knn_n}x{d}", "value": args.knn_nq / per, "unit": "queries/s",
            "nq": args.knn_nq, "k": k, "ms_per_search": per * 1e3, "n_total": args.knn_n, "rows_per_gpu": hi - lo,
            "collective": "none" if world == 1 else "all_gather_into_tensor (RCCL) of nq*k*16 B per rank"}

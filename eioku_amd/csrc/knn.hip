@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64) void k_topk_merge(const float* pd, const int* p
 
 
 // ---------------------------------------------------------------------------------------------
-// Scan path (nq > 64, large N): database tiles stationary in registers.
+// Scan path (large N, any nq): database tiles stationary in registers.
 //
 // The kernels above keep a 32-query tile in registers and stream the database past it, so a 1024-query
 // search reads the database 8 times (once per 128 queries).  Here the roles are swapped: a wave keeps a tile
@@ -1053,6 +1053,10 @@ struct eioku_index {
   int scan_cap = 4096;         // candidate slots per query
   long long scan_min_rows = 262144;
   long long scan_sample = 0;   // sample rows for the bound (0: automatic)
+  int scan_min_nq = 1;         // fewest queries that take the scan path.  One pass over the bf16 plane (half the bytes
+                               // of the fp32 rows) beats the register-tile kernels at EVERY nq once N >= scan_min_rows:
+                               // 10 M x 384: nq 1 / 64 = 1.53 / 1.70 ms against 3.79 / 7.92 ms; 262 144 rows: 0.29 / 0.40
+                               // against 0.32 / 0.41 ms (tools/knn_nq_sweep.py, profiles/r02_knn_nq_sweep.jsonl)
   int scan_prescan = 32;       // stride of the pre-scan's row tiles (0: no pre-scan, the sample alone bounds the scan)
   int scan_rt = 2;             // row tiles per wave: 2 (8 waves per workgroup; 2-3 % faster at 10 M x 384) or 1 (12 waves)
 };
@@ -1554,7 +1558,7 @@ int search_impl(eioku_index* ix, const float* q, int nq, int k, const float* lbD
     dD = ix->dout;
     dI = ix->iout;
   }
-  const bool scan = ix->scan_mode != 0 && !dlbD && nq > 64 && k >= 2 && k <= 16 && ix->n >= ix->scan_min_rows &&
+  const bool scan = ix->scan_mode != 0 && !dlbD && nq >= ix->scan_min_nq && k >= 2 && k <= 16 && ix->n >= ix->scan_min_rows &&
                     (d == 128 || d == 256 || d == 384);
   if (scan) {
     // groups of <= 1024 queries: their planes (<= 1.5 MB) stay in every XCD's L2 while the rows stream past
@@ -1608,6 +1612,9 @@ int eioku_index_set_param(eioku_index* ix, const char* name, long long value) {
   } else if (!strcmp(name, "scan_sample")) {
     EIOKU_REQUIRE(value >= 0, "scan_sample must be >= 0");
     ix->scan_sample = value;
+  } else if (!strcmp(name, "scan_min_nq")) {
+    EIOKU_REQUIRE(value >= 1, "scan_min_nq must be >= 1");
+    ix->scan_min_nq = (int)value;
   } else if (!strcmp(name, "scan_prescan")) {
     EIOKU_REQUIRE(value == 0 || (value >= 2 && value <= 1024), "scan_prescan is 0 (off) or a tile stride in [2, 1024]");
     ix->scan_prescan = (int)value;

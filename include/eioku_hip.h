@@ -220,7 +220,7 @@ int eioku_index_search(eioku_index_t* ix, const float* q, int nq, int k, float* 
 int eioku_index_search_after(eioku_index_t* ix, const float* q, int nq, int k, const float* after_D,
                              const int64_t* after_I, float* D, int64_t* I, int mem, void* stream);
 /* Tuning / test knobs of the wide-search ("scan") path, see csrc/knn.hip: "scan_mode" 0 = register-tile kernels only,
- * 1 (default) = searches with nq > 64 over >= "scan_min_rows" rows keep row tiles stationary, filter with one bf16
+ * 1 (default) = searches of >= "scan_min_nq" (default 1) queries over >= "scan_min_rows" rows keep row tiles stationary, filter with one bf16
  * product term and re-rank the candidates in fp32; "scan_cap" candidate slots per query (a list that overflows falls
  * back to the register-tile kernels); "scan_sample" rows of the bounding sample (0 = automatic); "scan_prescan" stride of the row tiles the
  * scan visits FIRST to tighten that bound (default 32; 0 = off, the sample alone bounds the scan); "scan_rt" 1 or 2

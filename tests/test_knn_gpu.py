@@ -148,6 +148,7 @@ def test_full_size_properties_1m(gpu):
     for r in range(4):
         lo, hi = search.shard_bounds(n, 4, r)
         s = search.IndexFlatL2(d)
+        s.set_param("scan_min_rows", 4096)  # 250 k rows: the same search path as the whole index, so the same bytes
         s.attach(xb[lo:hi])
         Ds, Is = s.search(q, k)
         dl.append(Ds)
