@@ -1558,7 +1558,7 @@ int search_impl(eioku_index* ix, const float* q, int nq, int k, const float* lbD
     dD = ix->dout;
     dI = ix->iout;
   }
-  const bool scan = ix->scan_mode != 0 && !dlbD && nq >= ix->scan_min_nq && k >= 2 && k <= 16 && ix->n >= ix->scan_min_rows &&
+  const bool scan = ix->scan_mode != 0 && !dlbD && nq >= ix->scan_min_nq && k <= 32 && ix->n >= ix->scan_min_rows &&
                     (d == 128 || d == 256 || d == 384);
   if (scan) {
     // groups of <= 1024 queries: their planes (<= 1.5 MB) stay in every XCD's L2 while the rows stream past

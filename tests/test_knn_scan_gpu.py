@@ -30,7 +30,7 @@ def scan_index(d, mode=1, **params):
     (20000, 70, 10, 384, 1), (5000, 130, 10, 128, 1), (33333, 200, 16, 256, 1), (4099, 65, 2, 384, 1),
     (50001, 97, 10, 384, 1), (8192, 1024, 10, 384, 1), (50001, 300, 10, 384, 1), (40000, 129, 10, 128, 1),
     (70001, 257, 10, 384, 2), (50033, 300, 10, 384, 2), (20000, 100, 10, 128, 2), (45000, 200, 10, 256, 2),
-    (4096, 66, 5, 384, 2),
+    (4096, 66, 5, 384, 2), (30000, 40, 1, 384, 2), (30000, 100, 32, 384, 2), (25000, 7, 24, 128, 1), (6000, 5, 1, 256, 2),
 ])
 def test_scan_matches_float64_truth(gpu, n, nq, k, d, rt):
     xb = unit_rows(31, n, d)
