@@ -147,16 +147,51 @@ struct SmallTop {
   }
 };
 
+// FAISS' precomputed-table decomposition of the ADC look-up table (IndexIVFPQ::use_precomputed_table = 1):
+//   || (q - c_l)_j - p_jc ||^2 = || (q - c_l)_j ||^2  +  ( ||p_jc||^2 + 2 c_l,j . p_jc )  +  ( -2 q_j . p_jc )
+// the middle term depends on (list, j, c) only - one table per index, built once - the last on (query, j, c) only -
+// one table per query and search - and the first sums over j to ||q - c_l||^2, a scalar per (query, list).  The
+// per-(query, list) table is then m x 256 additions of two streamed rows instead of m x 256 x dsub multiply-adds over
+// the whole PQ codebook (393 KB of L2 reads per workgroup at m = 48, dsub = 8: it cost as much as scanning the list).
+// out[v][j][c] = alpha ||p_jc||^2 + beta (vecs[v]_j . p_jc);  grid (nvec), block 256
+template <int DSUB>
+__global__ __launch_bounds__(256) void k_ivfpq_tables(const float* __restrict__ vecs, int d, int m,
+                                                      const float* __restrict__ pq, float alpha, float beta,
+                                                      float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sv[];  // the vector
+  const int v = blockIdx.x, tid = threadIdx.x;
+  for (int t = tid; t < d; t += 256) sv[t] = vecs[(size_t)v * d + t];
+  __syncthreads();
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int V4 = DSUB / 4;
+  const int nent = m * 256;
+  for (int e = tid; e < nent; e += 256) {
+    const int j = e >> 8;
+    float nn = 0.f, dp = 0.f;
+#pragma unroll
+    for (int t4 = 0; t4 < V4; ++t4) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(pq + (size_t)e * DSUB + t4 * 4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        nn += p[t] * p[t];
+        dp += sv[j * DSUB + t4 * 4 + t] * p[t];
+      }
+    }
+    out[(size_t)v * nent + e] = alpha * nn + beta * dp;
+  }
+}
+
 // grid (nq, nprobe); block 256.  probes: [nq][nprobe] list ids (-1 = none).
 // out: pd/pi [nprobe][nq][K]  (the [list][nq][k] layout k_topk_merge takes)
-template <int K, int DSUB>
+template <int K, int DSUB, bool PRE = false>
 __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q, int nq, int d, int m,
                                                     const long long* __restrict__ probes, int nprobe,
                                                     const float* __restrict__ coarse, const float* __restrict__ pq,
                                                     const int* __restrict__ offsets, const int* __restrict__ sizes,
                                                     const uint8_t* __restrict__ list_codes,
                                                     const long long* __restrict__ list_ids, float* __restrict__ pd,
-                                                    long long* __restrict__ pi) {
+                                                    long long* __restrict__ pi, const float* __restrict__ t2 = nullptr,
+                                                    const float* __restrict__ t3 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lut[];  // [m][256], then merge area
   const int qi = blockIdx.x, pr = blockIdx.y, tid = threadIdx.x;
   const long long l = probes[(size_t)qi * nprobe + pr];
@@ -167,11 +202,25 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q,
     float* rq = lut + (size_t)m * 256;
     for (int t = tid; t < d; t += 256) rq[t] = q[(size_t)qi * d + t] - coarse[(size_t)l * d + t];
     __syncthreads();
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int nent = m * 256;
+    float term1 = 0.f;  // PRE: || q - c_l ||^2, added to every distance of the list
+    if (PRE) {
+      // LUT[e] = T2[l][e] + T3[q][e]: two coalesced rows, 16 bytes per lane and load
+      __shared__ float s_part[4];
+      const f32x4* a = reinterpret_cast<const f32x4*>(t2 + (size_t)l * nent);
+      const f32x4* b = reinterpret_cast<const f32x4*>(t3 + (size_t)qi * nent);
+      for (int e4 = tid; e4 < nent / 4; e4 += 256) reinterpret_cast<f32x4*>(lut)[e4] = a[e4] + b[e4];
+      float part = 0.f;
+      for (int t = tid; t < d; t += 256) part += rq[t] * rq[t];
+      part = wave_reduce_add(part);
+      if ((tid & 63) == 0) s_part[tid >> 6] = part;
+      __syncthreads();
+      term1 = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    } else {
     // LUT[j][c] = || r_j - pq[j][c] ||^2 : 16-byte loads, LB entries in flight per thread (one entry per loop
     // iteration was 48 dependent L2 round trips per workgroup), same summation order as before
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int V4 = DSUB / 4, LB = 8;
-    const int nent = m * 256;
     for (int e0 = 0; e0 < nent; e0 += 256 * LB) {
       f32x4 rows[LB][V4];
 #pragma unroll
@@ -197,6 +246,7 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q,
         }
         if (e < nent) lut[e] = s;
       }
+    }
     }
     __syncthreads();
     const int off = offsets[l], sz = sizes[l];
@@ -231,14 +281,14 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q,
             for (int b = 0; b < 16; ++b) s += lut[(w * 16 + b) * 256 + ((c[w][b >> 2] >> (8 * (b & 3))) & 0xFFu)];
           }
         }
-        top.insert(s, id);
+        top.insert(PRE ? s + term1 : s, id);
       }
     } else {
       for (int i = tid; i < sz; i += 256) {
         const uint8_t* code = list_codes + (size_t)(off + i) * m;
         float s = 0.f;
         for (int j = 0; j < m; ++j) s += lut[j * 256 + code[j]];
-        top.insert(s, list_ids[off + i]);
+        top.insert(PRE ? s + term1 : s, list_ids[off + i]);
       }
     }
   }
@@ -405,15 +455,36 @@ int eioku_ivf_scatter(const long long* list_dev, long long n, int m, const uint8
   return EIOKU_OK;
 }
 
-// ADC scan of the probed lists.  Partial results pd/pi are [nprobe][nq][K] with K = 16 (k <= 16) or 32;
-// merge them with eioku_topk_merge(pd, pi, nprobe, nq, K -> k ...).
-int eioku_ivfpq_scan(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe,
-                     const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
-                     const uint8_t* list_codes_dev, const long long* list_ids_dev, int k, float* pd_dev,
-                     long long* pi_dev, void* stream_) {
+// out[v][j][c] = alpha ||pq[j][c]||^2 + beta (vecs[v]_j . pq[j][c]), [nvec][m][256] floats.  The two tables of the
+// precomputed-table scan: per list (vecs = coarse centroids, alpha 1, beta 2; once per index) and per query
+// (vecs = queries, alpha 0, beta -2; once per search).
+int eioku_ivfpq_tables(const float* vecs_dev, int nvec, int d, int m, const float* pq_dev, float alpha, float beta,
+                       float* out_dev, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(vecs_dev && pq_dev && out_dev && nvec >= 0 && m > 0 && d % m == 0, "bad argument");
+  const int dsub = d / m;
+  EIOKU_REQUIRE(dsub == 4 || dsub == 8 || dsub == 16, "sub-vector size %d not supported (4, 8, 16)", dsub);
+  if (nvec == 0) return EIOKU_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t lds = (size_t)d * 4;
+  if (dsub == 4) hipLaunchKernelGGL(k_ivfpq_tables<4>, dim3(nvec), dim3(256), lds, stream, vecs_dev, d, m, pq_dev, alpha, beta, out_dev);
+  else if (dsub == 8) hipLaunchKernelGGL(k_ivfpq_tables<8>, dim3(nvec), dim3(256), lds, stream, vecs_dev, d, m, pq_dev, alpha, beta, out_dev);
+  else hipLaunchKernelGGL(k_ivfpq_tables<16>, dim3(nvec), dim3(256), lds, stream, vecs_dev, d, m, pq_dev, alpha, beta, out_dev);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+}  // extern "C"
+
+namespace {
+int scan_launch(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe,
+                const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
+                const uint8_t* list_codes_dev, const long long* list_ids_dev, int k, float* pd_dev,
+                long long* pi_dev, const float* t2_dev, const float* t3_dev, void* stream_) {
   EIOKU_REQUIRE_INIT();
   EIOKU_REQUIRE(q_dev && probes_dev && coarse_dev && pq_dev && offsets_dev && sizes_dev && pd_dev && pi_dev, "NULL buffer");
   EIOKU_REQUIRE(nq >= 0 && nprobe > 0 && k >= 1 && k <= 32 && d % m == 0, "bad argument");
+  EIOKU_REQUIRE((t2_dev == nullptr) == (t3_dev == nullptr), "the list table and the query table come together");
   const int dsub = d / m;
   EIOKU_REQUIRE(dsub == 4 || dsub == 8 || dsub == 16, "sub-vector size %d not supported (4, 8, 16)", dsub);
   if (nq == 0) return EIOKU_OK;
@@ -424,25 +495,54 @@ int eioku_ivfpq_scan(const float* q_dev, int nq, int d, int m, const long long* 
   if (merge > lds) lds = merge;
   EIOKU_REQUIRE(lds <= 150 * 1024, "m=%d needs %zu bytes of LDS", m, lds);
   dim3 grid((unsigned)nq, (unsigned)nprobe);
-#define EIOKU_SCAN(K_, D_)                                                                                     \
+  const bool pre = t2_dev != nullptr;
+#define EIOKU_SCAN1(K_, D_, P_)                                                                                \
   {                                                                                                            \
     static bool attr = false;                                                                                  \
     if (!attr) {                                                                                               \
-      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ivfpq_scan<K_, D_>),                 \
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ivfpq_scan<K_, D_, P_>),             \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));            \
       attr = true;                                                                                             \
     }                                                                                                          \
-    hipLaunchKernelGGL((k_ivfpq_scan<K_, D_>), grid, dim3(256), lds, stream, q_dev, nq, d, m, probes_dev, nprobe, \
-                       coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev, list_ids_dev, pd_dev, pi_dev); \
+    hipLaunchKernelGGL((k_ivfpq_scan<K_, D_, P_>), grid, dim3(256), lds, stream, q_dev, nq, d, m, probes_dev, nprobe, \
+                       coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev, list_ids_dev, pd_dev, pi_dev, \
+                       t2_dev, t3_dev);                                                                        \
   }
+#define EIOKU_SCAN(K_, D_) \
+  if (pre) EIOKU_SCAN1(K_, D_, true) else EIOKU_SCAN1(K_, D_, false)
   if (K == 16) {
     if (dsub == 4) EIOKU_SCAN(16, 4) else if (dsub == 8) EIOKU_SCAN(16, 8) else EIOKU_SCAN(16, 16)
   } else {
     if (dsub == 4) EIOKU_SCAN(32, 4) else if (dsub == 8) EIOKU_SCAN(32, 8) else EIOKU_SCAN(32, 16)
   }
 #undef EIOKU_SCAN
+#undef EIOKU_SCAN1
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// ADC scan of the probed lists.  Partial results pd/pi are [nprobe][nq][K] with K = 16 (k <= 16) or 32;
+// merge them with eioku_topk_merge(pd, pi, nprobe, nq, K -> k ...).
+int eioku_ivfpq_scan(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe,
+                     const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
+                     const uint8_t* list_codes_dev, const long long* list_ids_dev, int k, float* pd_dev,
+                     long long* pi_dev, void* stream_) {
+  return scan_launch(q_dev, nq, d, m, probes_dev, nprobe, coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev,
+                     list_ids_dev, k, pd_dev, pi_dev, nullptr, nullptr, stream_);
+}
+
+// the same scan with the look-up tables assembled from eioku_ivfpq_tables' outputs: list_tables [nlist][m][256] (alpha 1,
+// beta 2 over the coarse centroids), query_tables [nq][m][256] (alpha 0, beta -2 over the queries)
+int eioku_ivfpq_scan_tables(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe,
+                            const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
+                            const uint8_t* list_codes_dev, const long long* list_ids_dev, const float* list_tables_dev,
+                            const float* query_tables_dev, int k, float* pd_dev, long long* pi_dev, void* stream_) {
+  EIOKU_REQUIRE(list_tables_dev && query_tables_dev, "NULL table");
+  return scan_launch(q_dev, nq, d, m, probes_dev, nprobe, coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev,
+                     list_ids_dev, k, pd_dev, pi_dev, list_tables_dev, query_tables_dev, stream_);
 }
 
 }  // extern "C"

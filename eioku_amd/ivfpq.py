@@ -136,6 +136,8 @@ class IndexIVFPQ:
         self._pending = []          # (list int64, codes uint8, id_base) per add() batch
         self.ntotal = 0
         self._packed = None
+        self.use_precomputed_table = True   # FAISS' IndexIVFPQ.use_precomputed_table; False = tables from the codebook per (query, list)
+        self._list_tables = None
         self.allreduce_calls = 0
 
     # ---- training ------------------------------------------------------------------------------
@@ -197,6 +199,7 @@ class IndexIVFPQ:
             packed = self._allreduce(packed.contiguous(), group)  # (m, 256, dsub + 1): one collective for all sub-quantisers
             pq = torch.stack([ops.finalize(packed[j], pq[j].contiguous()) for j in range(self.m)]).contiguous()
         self.pq = pq
+        self._list_tables = None
         if self._lib is not None:
             self._quantizer = IndexFlatL2(self.d)
             self._quantizer.attach(self.coarse)
@@ -208,6 +211,7 @@ class IndexIVFPQ:
 
         self.coarse = torch.as_tensor(coarse, dtype=torch.float32).to(self.device).contiguous()
         self.pq = torch.as_tensor(pq, dtype=torch.float32).to(self.device).contiguous()
+        self._list_tables = None
         if self._quantizer is not None:
             self._quantizer.close()
         self._quantizer = IndexFlatL2(self.d)
@@ -268,9 +272,24 @@ class IndexIVFPQ:
         K = 16 if k <= 16 else 32
         pd = torch.empty((nprobe, nq, K), dtype=torch.float32, device=self.device)
         pi = torch.empty((nprobe, nq, K), dtype=torch.int64, device=self.device)
-        _lib.check(self._lib.eioku_ivfpq_scan(ptr(q), nq, self.d, self.m, ptr(probes), nprobe, ptr(self.coarse), ptr(self.pq),
-                                              ptr(offsets), ptr(sizes), ptr(list_codes), ptr(list_ids), k, ptr(pd), ptr(pi),
-                                              current_stream(q)), "eioku_ivfpq_scan")
+        if self.use_precomputed_table:
+            # FAISS' decomposition: the per-list half of every look-up table is part of the index (nlist x m x 1 KB, built
+            # on the first search after the codebooks change), the per-query half is built once per search
+            if self._list_tables is None:
+                self._list_tables = torch.empty((self.nlist, self.m, 256), dtype=torch.float32, device=self.device)
+                _lib.check(self._lib.eioku_ivfpq_tables(ptr(self.coarse), self.nlist, self.d, self.m, ptr(self.pq), 1.0, 2.0,
+                                                        ptr(self._list_tables), current_stream(q)), "eioku_ivfpq_tables")
+            qt = torch.empty((nq, self.m, 256), dtype=torch.float32, device=self.device)
+            _lib.check(self._lib.eioku_ivfpq_tables(ptr(q), nq, self.d, self.m, ptr(self.pq), 0.0, -2.0, ptr(qt),
+                                                    current_stream(q)), "eioku_ivfpq_tables")
+            _lib.check(self._lib.eioku_ivfpq_scan_tables(ptr(q), nq, self.d, self.m, ptr(probes), nprobe, ptr(self.coarse),
+                                                         ptr(self.pq), ptr(offsets), ptr(sizes), ptr(list_codes), ptr(list_ids),
+                                                         ptr(self._list_tables), ptr(qt), k, ptr(pd), ptr(pi),
+                                                         current_stream(q)), "eioku_ivfpq_scan_tables")
+        else:
+            _lib.check(self._lib.eioku_ivfpq_scan(ptr(q), nq, self.d, self.m, ptr(probes), nprobe, ptr(self.coarse), ptr(self.pq),
+                                                  ptr(offsets), ptr(sizes), ptr(list_codes), ptr(list_ids), k, ptr(pd), ptr(pi),
+                                                  current_stream(q)), "eioku_ivfpq_scan")
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         _lib.check(self._lib.eioku_topk_merge_ex(ptr(pd), ptr(pi), nprobe, nq, K, k, ptr(D), ptr(I), current_stream(q)),

@@ -304,6 +304,18 @@ int eioku_ivfpq_scan(const float* q_dev, int nq, int d, int m, const long long* 
                      const float* coarse_dev, const float* pq_dev, const int* offsets_dev,
                      const int* sizes_dev, const uint8_t* list_codes_dev, const long long* list_ids_dev,
                      int k, float* pd_dev, long long* pi_dev, void* stream);
+/* FAISS' precomputed-table form of the same scan (IndexIVFPQ::use_precomputed_table): eioku_ivfpq_tables writes
+ * out[v][j][c] = alpha ||pq[j][c]||^2 + beta (vecs[v]_j . pq[j][c]) as [nvec][m][256] floats - once per index over the
+ * coarse centroids (alpha 1, beta 2: nlist x m x 1 KB) and once per search over the queries (alpha 0, beta -2) - and
+ * eioku_ivfpq_scan_tables assembles each (query, list) look-up table as the sum of two rows + ||q - c||^2 instead of
+ * m x 256 x dsub multiply-adds over the codebook.  Same results up to fp32 rounding of the decomposition. */
+int eioku_ivfpq_tables(const float* vecs_dev, int nvec, int d, int m, const float* pq_dev, float alpha, float beta,
+                       float* out_dev, void* stream);
+int eioku_ivfpq_scan_tables(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe,
+                            const float* coarse_dev, const float* pq_dev, const int* offsets_dev,
+                            const int* sizes_dev, const uint8_t* list_codes_dev, const long long* list_ids_dev,
+                            const float* list_tables_dev, const float* query_tables_dev, int k, float* pd_dev,
+                            long long* pi_dev, void* stream);
 
 #ifdef __cplusplus
 }

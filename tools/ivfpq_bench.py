@@ -45,15 +45,19 @@ def main():
     torch.cuda.synchronize()
     t_add = time.perf_counter() - t0
     ix.nprobe = nprobe
-    for _ in range(2):
-        D, I = ix.search(q, k)
-    torch.cuda.synchronize()
     iters = 5
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        D, I = ix.search(q, k)
-    torch.cuda.synchronize()
-    t_search = (time.perf_counter() - t0) / iters
+    times = {}
+    for pre in (False, True):  # look-up tables from the codebook per (query, list) / FAISS' precomputed-table form (default)
+        ix.use_precomputed_table = pre
+        for _ in range(2):
+            D, I = ix.search(q, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            D, I = ix.search(q, k)
+        torch.cuda.synchronize()
+        times[pre] = (time.perf_counter() - t0) / iters
+    t_search = times[True]
 
     flat = search.IndexFlatL2(d)
     flat.attach(xb)
@@ -63,11 +67,19 @@ def main():
     planted = (I == qa.unsqueeze(1)).any(dim=1).float().mean().item()
     planted_flat = (It[:, 0] == qa).float().mean().item()
     codes_scanned = float(n) / nlist * nprobe * nq * m  # bytes of PQ codes an ideal balanced index would read
+    # ... and what THIS index reads: the lists a query probes are the ones near database rows, i.e. the large ones
+    offsets, sizes, _, _ = ix._pack()
+    _, probes = ix._quantizer.search_many(q, nprobe)
+    actual = float(sizes.long()[probes.clamp(min=0)].sum().item()) * m
+    szs = sizes.float()
     print(json.dumps({"metric": "IVF-PQ build + search", "n": n, "d": d, "nlist": nlist, "m": m, "nprobe": nprobe, "nq": nq, "k": k,
                       "train_s": t_train, "add_s": t_add, "add_vectors_per_s": n / t_add, "search_ms": t_search * 1e3,
-                      "qps": nq / t_search, "recall_at_10_vs_flat": hit, "planted_neighbour_in_top10": planted,
+                      "qps": nq / t_search, "search_ms_tables_from_codebook": times[False] * 1e3, "recall_at_10_vs_flat": hit, "planted_neighbour_in_top10": planted,
                       "planted_neighbour_is_flat_top1": planted_flat,
-                      "code_bytes_per_search": codes_scanned, "code_GBps": codes_scanned / t_search / 1e9}))
+                      "code_bytes_per_search": codes_scanned, "code_GBps": codes_scanned / t_search / 1e9,
+                      "code_bytes_actually_scanned": actual, "actual_code_GBps": actual / t_search / 1e9,
+                      "list_size_mean_max": [float(szs.mean().item()), float(szs.max().item())],
+                      "mean_probed_list_size": actual / m / nq / nprobe}))
 
 
 main()
