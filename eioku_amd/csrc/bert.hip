@@ -779,13 +779,16 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
   lo[i] = l;
 }
 
-template <int EPI, bool WS, int BKS = 128>
+// WMT x WNT: 32x32 MFMA tiles per wave (the workgroup's tile is 64 WMT x 64 WNT).  1 x 1 for the small-M ingest path
+// (more workgroups); 2 x 2 for M >= 8192: 8 LDS fragment reads per 12 MFMAs instead of 16, and every activation value
+// is split into its bf16 terms by N / 128 workgroups instead of N / 64 (the split's VALU ran level with the MFMAs).
+template <int EPI, bool WS, int BKS = 128, int WMT = 1, int WNT = 1>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                       const unsigned short* __restrict__ Whi,
                                                       const unsigned short* __restrict__ Wlo,
                                                       const float* __restrict__ bias, float* __restrict__ C, int ldc,
                                                       int M, int N, int K, int kstages) {
-  constexpr int BM = 64, BN = 64;
+  constexpr int BM = 64 * WMT, BN = 64 * WNT;
   constexpr int F4R = BKS / 4, RSTEP = 256 / F4R;  // float4 per staged row; rows covered by one pass of the 256 threads
   constexpr int PPR = BKS / 8;   // 8-k units per row and plane
   constexpr int UPR = 2 * PPR;   // [hi plane | lo plane]
@@ -797,9 +800,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int half = lane >> 5, l31 = lane & 31;
-  f32x16 acc;
+  f32x16 acc[WMT][WNT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int sfu = tid & (F4R - 1), srow = tid / F4R;  // float4 index inside the staged row (k = 4 sfu ..), rows srow + RSTEP it
   const int k0 = blockIdx.z * kstages * BKS;
   f32x4 ra[RA], rw[WS ? 1 : RW];
@@ -852,30 +859,51 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
     commit();
     __syncthreads();
     if (st + 1 < kstages) issue(st + 1);
-    const int arow = wm * 32 + l31, wrow = wn * 32 + l31;
-    const u32x4b* ap = sA + arow * UPR;
-    const u32x4b* wp = sW + wrow * UPR;
 #pragma unroll
     for (int s8 = 0; s8 < BKS / 16; ++s8) {
-      const int pa = (2 * s8 + half) ^ (arow & (PPR - 1)), pw = (2 * s8 + half) ^ (wrow & (PPR - 1));
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, ap[pa]), al = __builtin_bit_cast(bf16x8, ap[PPR + pa]);
-      const bf16x8 wh = __builtin_bit_cast(bf16x8, wp[pw]), wl = __builtin_bit_cast(bf16x8, wp[PPR + pw]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+      bf16x8 ah[WMT], al[WMT], wh[WNT], wl[WNT];
+#pragma unroll
+      for (int i = 0; i < WMT; ++i) {
+        const int arow = (wm * WMT + i) * 32 + l31;
+        const u32x4b* ap = sA + arow * UPR;
+        const int pa = (2 * s8 + half) ^ (arow & (PPR - 1));
+        ah[i] = __builtin_bit_cast(bf16x8, ap[pa]);
+        al[i] = __builtin_bit_cast(bf16x8, ap[PPR + pa]);
+      }
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int wrow = (wn * WNT + j) * 32 + l31;
+        const u32x4b* wp = sW + wrow * UPR;
+        const int pw = (2 * s8 + half) ^ (wrow & (PPR - 1));
+        wh[j] = __builtin_bit_cast(bf16x8, wp[pw]);
+        wl[j] = __builtin_bit_cast(bf16x8, wp[PPR + pw]);
+      }
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], wh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+        }
     }
     __syncthreads();
   }
-  const int n = n0 + wn * 32 + l31;
-  const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (m < M) {
-      float v = acc[r] + bv;
-      if (EPI == 1) v = gelu_erf(v);
-      C[(size_t)m * ldc + n] = v;
-    }
+  for (int j = 0; j < WNT; ++j) {
+    const int n = n0 + (wn * WNT + j) * 32 + l31;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * WMT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < M) {
+          float v = acc[i][j][r] + bv;
+          if (EPI == 1) v = gelu_erf(v);
+          C[(size_t)m * ldc + n] = v;
+        }
+      }
   }
 }
 
@@ -949,7 +977,18 @@ int gemm(const float* A, int lda, const float* W, const float* bias, float* C, i
     }
     const unsigned short* whi = ws ? ws->hi : nullptr;
     const unsigned short* wlo = ws ? ws->lo : nullptr;
-    if (bf && whi && bks64 && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, true, 64>), grid, dim3(256), lds / 2, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages * 2);
+    if (bf && whi && M >= 8192 && N % 128 == 0 && splits == 1) {
+      // 128 x 128 tiles, 64-deep stages (64 KB of LDS, two workgroups per CU)
+      static bool attr3 = false;
+      if (!attr3) {
+        EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<0, true, 64, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<1, true, 64, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr3 = true;
+      }
+      dim3 grid2((unsigned)((M + 127) / 128), (unsigned)(N / 128), 1u);
+      if (epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, true, 64, 2, 2>), grid2, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages * 2);
+      else hipLaunchKernelGGL((k_gemm_bf_s<0, true, 64, 2, 2>), grid2, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages * 2);
+    } else if (bf && whi && bks64 && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, true, 64>), grid, dim3(256), lds / 2, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages * 2);
     else if (bf && whi && bks64) hipLaunchKernelGGL((k_gemm_bf_s<0, true, 64>), grid, dim3(256), lds / 2, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages * 2);
     else if (bf && whi && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, true>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
     else if (bf && whi) hipLaunchKernelGGL((k_gemm_bf_s<0, true>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
