@@ -48,7 +48,11 @@ struct FusedInput {
   int src_h, src_w;     // original frame
   int new_h, new_w;     // resized (unpadded) size
   int top, left;        // padding offsets
-  int mode;             // LetterboxPlan::mode, 0 or 2
+  int mode;             // 0: copy, 2: exact-1/2 area average
+  // mode 0 only: letterboxed pixel (y, x) of the image region is source pixel (step y + off, step x + off).  1 / 0 = the
+  // plain copy; step 3, off 1 = cv2.INTER_LINEAR at an exact 1/3 scale (1080p -> 360 x 640), whose tap weights are
+  // (1, 0) everywhere: a decimation
+  int step = 1, off = 0;
 };
 bool fused_input_ok(const ConvWeights& cw, const FusedInput& f, Slice res, const float* out_f32);
 // `up` (1x1 only): the first c_split input channels are the nearest-2x upsample of `src` (half resolution), read in

@@ -1118,6 +1118,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, 
 struct FusedSrc {
   const uint8_t* bgr;
   int src_h, src_w, new_h, new_w, top, left;
+  int step = 1, off = 0;  // SRC 1: source pixel of image pixel (y, x) = (step y + off, step x + off)
 };
 
 template <int NF, int S, int SRC>
@@ -1212,7 +1213,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
         s_img |= (img ? 1u : 0u) << j;
         const uint8_t* f = fs.bgr + (size_t)nx_n * fs.src_h * fs.src_w * 3;
         if (SRC == 1) {
-          const uint8_t* p = f + (img ? ((size_t)y * fs.src_w + x) * 3 : 0);
+          const uint8_t* p = f + (img ? ((size_t)(y * fs.step + fs.off) * fs.src_w + (x * fs.step + fs.off)) * 3 : 0);
 #pragma unroll
           for (int c = 0; c < 3; ++c) raw[j][c] = p[c];
         } else {
@@ -2094,7 +2095,7 @@ bool conv_stem_chain_ok(const ConvWeights& stem, const ConvWeights& c1, const Co
                       c1.ks == 3 && c1.stride == 2 && c1.cin == 16 && c1.cout == 32 && c1.nf == 2 && c1.ntiles == 1 &&
                       c1.nchunks == 1 && post.ks == 1 && post.cin == 32 && post.cout == 32 && post.nf == 2 && post.ntiles == 1;
   // copy-mode letterbox whose rows and padding are 4-pixel aligned (12-byte group loads)
-  const bool src = f.bgr != nullptr && f.mode == 0 && f.src_w % 4 == 0 && f.left % 4 == 0 && f.new_w % 4 == 0 && W % 4 == 0 &&
+  const bool src = f.bgr != nullptr && f.mode == 0 && f.step == 1 && f.src_w % 4 == 0 && f.left % 4 == 0 && f.new_w % 4 == 0 && W % 4 == 0 &&
                    ((uintptr_t)f.bgr & 3) == 0;
   return shapes && src;
 }
@@ -2211,10 +2212,11 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
     FusedSrc fs{};
     int src = 0;
     if (fused) {
-      fs = FusedSrc{fused->bgr, fused->src_h, fused->src_w, fused->new_h, fused->new_w, fused->top, fused->left};
+      fs = FusedSrc{fused->bgr, fused->src_h, fused->src_w, fused->new_h, fused->new_w, fused->top, fused->left,
+                    fused->mode == 0 ? fused->step : 1, fused->mode == 0 ? fused->off : 0};
       src = fused->mode == 0 ? 1 : 2;
       // copy mode with 4-pixel aligned rows and padding: 12-byte group loads instead of byte loads
-      if (src == 1 && fused->src_w % 4 == 0 && fused->left % 4 == 0 && fused->new_w % 4 == 0 && W % 4 == 0 &&
+      if (src == 1 && fused->step == 1 && fused->src_w % 4 == 0 && fused->left % 4 == 0 && fused->new_w % 4 == 0 && W % 4 == 0 &&
           ((uintptr_t)fused->bgr & 3) == 0)
         src = 3;
     }

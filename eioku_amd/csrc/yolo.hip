@@ -695,7 +695,22 @@ int eioku_yolo_detect(eioku_yolo* y, const uint8_t* bgr, int n, int h, int w, co
   }
   // copy / exact-half letterbox modes: the stem reads the frames itself (the fp16 network input, 6.5 MB per
   // 640x640 frame, is never written or read); the bilinear mode keeps K3 as its own pass
-  FusedInput fi{d_bgr, p.src_h, p.src_w, p.new_h, p.new_w, p.top, p.left, p.mode};
+  // cv2.INTER_LINEAR at an exact odd integer scale k samples source pixel k d + (k - 1) / 2 with tap weights (1, 0) -
+  // 1080p -> 360 x 640 is k = 3 - and K3 with such tables returns the source bytes themselves (its fixed-point
+  // arithmetic is the identity on weights (2048, 0) x (2048, 0)): the stem can read the frames as a strided copy
+  int step = 1, off = 0;
+  if (p.mode == 1 && p.new_w > 1 && p.new_h > 1) {
+    const int k = xofs[1] - xofs[0];
+    bool decim = k >= 2 && yofs[1] - yofs[0] == k && xofs[0] == yofs[0] && xofs[0] >= 0 &&
+                 (long long)k * (p.new_w - 1) + xofs[0] < w && (long long)k * (p.new_h - 1) + yofs[0] < h;
+    for (int i = 0; decim && i < p.new_w; ++i) decim = xofs[i] == k * i + xofs[0] && xalpha[2 * i] == 2048 && xalpha[2 * i + 1] == 0;
+    for (int j = 0; decim && j < p.new_h; ++j) decim = yofs[j] == k * j + yofs[0] && ybeta[2 * j] == 2048 && ybeta[2 * j + 1] == 0;
+    if (decim) {
+      step = k;
+      off = xofs[0];
+    }
+  }
+  FusedInput fi{d_bgr, p.src_h, p.src_w, p.new_h, p.new_w, p.top, p.left, step > 1 ? 0 : p.mode, step, off};
   const Op& op0 = y->ops.front();
   static const bool no_fuse = getenv("EIOKU_STEM_FUSE") && atoi(getenv("EIOKU_STEM_FUSE")) == 0;
   const bool fuse = !no_fuse && op0.kind == kConv && op0.in_buf == y->in_buf && op0.res_buf < 0 && op0.f32_out < 0 &&

@@ -323,7 +323,8 @@ def test_detect_fusion_switches_leave_the_detections_byte_identical(gpu, tmp_pat
             assert np.array_equal(a, b), name
 
 
-@pytest.mark.parametrize("h,w", [(470, 640), (640, 470), (640, 472), (940, 1280), (1280, 940), (96, 160)])
+@pytest.mark.parametrize("h,w", [(470, 640), (640, 470), (640, 472), (940, 1280), (1280, 940), (96, 160),
+                                 (1080, 1920), (1920, 1080), (960, 1920), (1605, 1920)])  # exact 1/3: a decimating copy
 def test_fused_stem_equals_letterbox_then_network(gpu, h, w):
     """detect() lets the stem read the BGR frames itself in the copy / exact-half letterbox modes (the fp16
     network input is never materialised); K3 -> eioku_yolo_forward -> K6/K7 is the unfused route.  Same
