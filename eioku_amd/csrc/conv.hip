@@ -1361,6 +1361,10 @@ constexpr int kSC_P1_U = (kSP_SLOTS + 1) * 2;       // + one spare slot
 constexpr int kSC_XS_U = (kSX_PX + 2) / 2 + 1;      // + spare pixel, 16 B units
 constexpr size_t kStemChainLds = (size_t)(kSC_WT1 + kSC_WT2 + kSC_T + kSC_P1_U + kSC_XS_U) * 16;
 
+// DECIM: the image region is a strided sampling of the source (FusedInput::step / off: 1080p -> 360 x 640 is step 3,
+// off 1): the 4 pixels of a group are 4 unaligned dword loads (3 bytes each + one ignored) instead of one dwordx3
+typedef unsigned u32_unaligned __attribute__((aligned(1)));
+template <bool DECIM>
 __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st, FusedSrc fs, int total_tiles) {
   constexpr int GPR = 18;                 // 4-pixel groups per patch row: columns -1 .. 70
   constexpr int NG = kSX_H * GPR;         // 630
@@ -1392,7 +1396,7 @@ __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st
   }
   const int tiles_per_img = a.tiles_w * a.tiles_h;
   const float r_tpi = 1.0f / (float)tiles_per_img, r_tw = 1.0f / (float)a.tiles_w;
-  u32x3 graw[RG];
+  u32x4 graw[RG];  // !DECIM: 12 packed bytes in [0..2]; DECIM: one pixel per dword
   unsigned s_in = 0, s_img = 0;
   bool s_full = false;
   int nx_n = 0, nx_th = 0, nx_tw = 0;
@@ -1414,7 +1418,15 @@ __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st
       const bool img = in && (unsigned)y < (unsigned)fs.new_h && (unsigned)x < (unsigned)fs.new_w;
       s_in |= (in ? 1u : 0u) << j;
       s_img |= (img ? 1u : 0u) << j;
-      graw[j] = *reinterpret_cast<const u32x3*>(fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + y) * fs.src_w + x) * 3 : 0));
+      if (DECIM) {
+        const uint8_t* p = fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + y * fs.step + fs.off) * fs.src_w + x * fs.step + fs.off) * 3 : 0);
+        const int ps = img ? fs.step * 3 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) graw[j][i] = *reinterpret_cast<const u32_unaligned*>(p + i * ps);
+      } else {
+        const u32x3 g = *reinterpret_cast<const u32x3*>(fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + y) * fs.src_w + x) * 3 : 0));
+        graw[j] = u32x4{g[0], g[1], g[2], 0};
+      }
     }
   };
 
@@ -1502,7 +1514,7 @@ __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st
           float v[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const int byte = 3 * i + c;
+            const int byte = DECIM ? 4 * i + c : 3 * i + c;
             const float fb = (float)((graw[j][byte >> 2] >> (8 * (byte & 3))) & 0xffu);
             v[c] = (FULL || img) ? fb : 114.0f;
           }
@@ -2095,8 +2107,10 @@ bool conv_stem_chain_ok(const ConvWeights& stem, const ConvWeights& c1, const Co
                       c1.ks == 3 && c1.stride == 2 && c1.cin == 16 && c1.cout == 32 && c1.nf == 2 && c1.ntiles == 1 &&
                       c1.nchunks == 1 && post.ks == 1 && post.cin == 32 && post.cout == 32 && post.nf == 2 && post.ntiles == 1;
   // copy-mode letterbox whose rows and padding are 4-pixel aligned (12-byte group loads)
-  const bool src = f.bgr != nullptr && f.mode == 0 && f.step == 1 && f.src_w % 4 == 0 && f.left % 4 == 0 && f.new_w % 4 == 0 && W % 4 == 0 &&
-                   ((uintptr_t)f.bgr & 3) == 0;
+  // (a decimating copy loads pixel by pixel: no alignment of the source, but the groups still must not straddle the
+  // image edge)
+  const bool src = f.bgr != nullptr && f.mode == 0 && f.left % 4 == 0 && f.new_w % 4 == 0 && W % 4 == 0 &&
+                   (f.step > 1 || (f.src_w % 4 == 0 && ((uintptr_t)f.bgr & 3) == 0));
   return shapes && src;
 }
 
@@ -2126,11 +2140,13 @@ int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, cons
   a.post_cout = post.cout;
   a.post_act = act2;
   StemArgs st{reinterpret_cast<const uint4*>(stem.d_w), stem.d_b, act0, H, W};
-  FusedSrc fs{f.bgr, f.src_h, f.src_w, f.new_h, f.new_w, f.top, f.left};
+  FusedSrc fs{f.bgr, f.src_h, f.src_w, f.new_h, f.new_w, f.top, f.left, f.step, f.off};
   static bool attr_set = false;
   if (!attr_set) {
-    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_stem_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)kStemChainLds));
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_stem_chain<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStemChainLds));
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_stem_chain<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStemChainLds));
     attr_set = true;
   }
   const int total = a.tiles_w * a.tiles_h * N;
@@ -2138,7 +2154,8 @@ int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, cons
   int bx = num_cus() * per_cu;
   if (bx > total) bx = total;
   prof_start(EIOKU_PROF_CONV, stream);
-  hipLaunchKernelGGL(k_conv_stem_chain, dim3((unsigned)bx), dim3(256), kStemChainLds, stream, a, st, fs, total);
+  if (f.step > 1) hipLaunchKernelGGL(k_conv_stem_chain<true>, dim3((unsigned)bx), dim3(256), kStemChainLds, stream, a, st, fs, total);
+  else hipLaunchKernelGGL(k_conv_stem_chain<false>, dim3((unsigned)bx), dim3(256), kStemChainLds, stream, a, st, fs, total);
   EIOKU_LAUNCH_CHECK();
   prof_stop(EIOKU_PROF_CONV, stream);
   return EIOKU_OK;

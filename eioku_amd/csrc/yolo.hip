@@ -702,7 +702,8 @@ int eioku_yolo_detect(eioku_yolo* y, const uint8_t* bgr, int n, int h, int w, co
   if (p.mode == 1 && p.new_w > 1 && p.new_h > 1) {
     const int k = xofs[1] - xofs[0];
     bool decim = k >= 2 && yofs[1] - yofs[0] == k && xofs[0] == yofs[0] && xofs[0] >= 0 &&
-                 (long long)k * (p.new_w - 1) + xofs[0] < w && (long long)k * (p.new_h - 1) + yofs[0] < h;
+                 // (the last sampled pixel of a row is followed by another one: the fused front end loads 4 bytes per pixel)
+                 (long long)k * (p.new_w - 1) + xofs[0] <= w - 2 && (long long)k * (p.new_h - 1) + yofs[0] < h;
     for (int i = 0; decim && i < p.new_w; ++i) decim = xofs[i] == k * i + xofs[0] && xalpha[2 * i] == 2048 && xalpha[2 * i + 1] == 0;
     for (int j = 0; decim && j < p.new_h; ++j) decim = yofs[j] == k * j + yofs[0] && ybeta[2 * j] == 2048 && ybeta[2 * j + 1] == 0;
     if (decim) {
