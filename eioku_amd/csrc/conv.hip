@@ -1115,6 +1115,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, 
 // staging slots read the BGR u8 frame (copy / exact 1/2 area modes of K3, same integer arithmetic,
 // same fp16 rounding of v/255, 114 grey outside the image) and build the unit on the way to LDS.
 // ---------------------------------------------------------------------------------------------
+typedef unsigned u32_unaligned __attribute__((aligned(1)));
 struct FusedSrc {
   const uint8_t* bgr;
   int src_h, src_w, new_h, new_w, top, left;
@@ -1214,8 +1215,14 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
         const uint8_t* f = fs.bgr + (size_t)nx_n * fs.src_h * fs.src_w * 3;
         if (SRC == 1) {
           const uint8_t* p = f + (img ? ((size_t)(y * fs.step + fs.off) * fs.src_w + (x * fs.step + fs.off)) * 3 : 0);
+          if (fs.step > 1) {  // a decimated pixel is never the last one of its row: one unaligned dword instead of 3 bytes
+            const unsigned v = *reinterpret_cast<const u32_unaligned*>(p);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) raw[j][c] = p[c];
+            for (int c = 0; c < 3; ++c) raw[j][c] = (v >> (8 * c)) & 0xffu;
+          } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) raw[j][c] = p[c];
+          }
         } else {
           const uint8_t* p0 = f + (img ? ((size_t)(2 * y) * fs.src_w + 2 * x) * 3 : 0);
           const uint8_t* p1 = p0 + (img ? (size_t)fs.src_w * 3 : 0);
@@ -1363,7 +1370,6 @@ constexpr size_t kStemChainLds = (size_t)(kSC_WT1 + kSC_WT2 + kSC_T + kSC_P1_U +
 
 // DECIM: the image region is a strided sampling of the source (FusedInput::step / off: 1080p -> 360 x 640 is step 3,
 // off 1): the 4 pixels of a group are 4 unaligned dword loads (3 bytes each + one ignored) instead of one dwordx3
-typedef unsigned u32_unaligned __attribute__((aligned(1)));
 template <bool DECIM>
 __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st, FusedSrc fs, int total_tiles) {
   constexpr int GPR = 18;                 // 4-pixel groups per patch row: columns -1 .. 70
