@@ -1,4 +1,4 @@
-# usage: tools/_call_b.sh <tag>: conv layer table of the detect-only forward -> gpurun_out/r02_conv_layers_<tag>.txt
+# usage (GPU box): tools/conv_layers.sh <tag>: per-layer conv table of the detect-only forward -> gpurun_out/r02_conv_layers_<tag>.txt
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=$1
 ARGS="$R/bench.py --steps 6 --warmup 3 --stages detect --knn-n 0 --no-cpu-baseline --overlap 0 --depth 1 --no-1080p"
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt &&
