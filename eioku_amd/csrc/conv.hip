@@ -1902,7 +1902,7 @@ int launch1x1_impl(const ConvArgs& a, int ntiles, int wg_cu, hipStream_t stream)
 // 64 MFMAs per pixel group and wave) are best with ONE workgroup per CU.
 template <int NF>
 int launch1x1(const ConvArgs& a, int ntiles, hipStream_t stream) {
-  const int wg = NF >= 8 ? 1 : 2;
+  const int wg = (NF >= 8 || (size_t)a.nchunks * 16 * NF * 64 > 80 * 1024) ? 1 : 2;
   return a.in2 ? launch1x1_impl<NF, true, 4>(a, ntiles, wg, stream) : launch1x1_impl<NF, false, 4>(a, ntiles, wg, stream);
 }
 
@@ -1946,7 +1946,9 @@ int pick_nf(int cout, int ks, int nchunks, int stride) {
     // 64 KB: with 96-128 KB tiles (NF = 8, 8 waves) the 384/512-channel 1x1 layers are 2-4 us faster each in an
     // isolated trace (-26 us per forward) but the overlapped step is not (40.5 vs 40.4 k frames/s) and the serial
     // profiled step is slower: a workgroup holding most of a CU's LDS keeps the other streams' kernels off that CU
-    constexpr int lim1 = 64;
+    // beyond 16 chunks (Cin > 512: YOLOv8m / l / x only) a 16-cout tile would re-read the whole input once per 16 couts
+    // (Cin = 1152 -> 576: 36 times): up to 128 KB there, one workgroup per CU
+    const int lim1 = nchunks > 16 ? 128 : 64;
     if (ks == 1 && nf * nchunks > lim1 && nf > 1) continue;  // 1x1: the whole Cin x tile weight block lives in LDS (nf*nchunks KB)
     int waste = ((frags + nf - 1) / nf) * nf - frags;
     if (waste < best_waste) {
@@ -2275,6 +2277,8 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
       rc = cw.stride == 1 ? launch_persist_dispatch<1>(cw.nf, cw.nchunks, db, a, cw.ntiles, stream, &handled)
                           : launch_persist_dispatch<2>(cw.nf, cw.nchunks, db, a, cw.ntiles, stream, &handled);
   }
+  // (YOLOv8m's 96 / 192-channel stride-2 convs at 80 / 40-wide maps have no persistent instantiation and fall through to
+  // the generic kernel, 200 TFLOP/s; sending them here with 16 staging slots measured the same: 370 vs 404 us)
   if (!handled && cw.ks == 3 && cw.nchunks > 3 && a.Wo <= 48)
     rc = cw.stride == 1 ? launch_flat_dispatch<1>(cw.nf, a, cw.ntiles, stream, &handled)
                         : launch_flat_dispatch<2>(cw.nf, a, cw.ntiles, stream, &handled);
