@@ -304,102 +304,6 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1(ConvArgs a, long long npix
   }
 }
 
-template <int NF, int KS, int S>
-__global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
-  constexpr int PH = (kTH - 1) * S + KS;
-  constexpr int PW = (kTW - 1) * S + KS;
-  constexpr int PWH = (PW + 1) / 2;            // S == 2: columns stored de-interleaved (even | odd)
-  constexpr int PWS = (S == 2) ? 2 * PWH : PW;  // LDS row pitch in pixels
-  constexpr int TAPS = KS * KS;
-  constexpr int PAD = KS / 2;
-  constexpr int PATCH_U = PH * PWS * 4;  // uint4 units
-  constexpr int WT_U = TAPS * 16 * NF * 4;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint4* patch = reinterpret_cast<uint4*>(smem);
-  uint4* wt = patch + PATCH_U;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bx = blockIdx.x;
-  const int tw = bx % a.tiles_w;
-  bx /= a.tiles_w;
-  const int th = bx % a.tiles_h;
-  const int n = bx / a.tiles_h;
-  const int oh0 = th * kTH, ow0 = tw * kTW;
-  const int ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
-  const int co_tile = blockIdx.y;
-
-  float4v acc[2][NF];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int f = 0; f < NF; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
-
-  const __half* in_n = a.in + (size_t)n * a.H * a.W * a.in_cs;
-  const uint4* wsrc = a.wgt + (size_t)co_tile * a.nchunks * WT_U;
-
-  for (int cc = 0; cc < a.nchunks; ++cc) {
-    // ---- 1. halo patch: HBM/L2 -> LDS, each input byte of the tile read once per chunk ----
-    for (int idx = tid; idx < PH * PW * 4; idx += 256) {
-      const int pix = idx >> 2, unit = idx & 3;
-      const int py = pix / PW, px = pix - py * PW;
-      const int ih = ih0 + py, iw = iw0 + px;
-      const int c = cc * 32 + unit * 8;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W && c < a.Cin)
-        v = *reinterpret_cast<const uint4*>(in_n + ((size_t)ih * a.W + iw) * a.in_cs + c);
-      const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
-      const int p = py * PWS + col;
-      patch[p * 4 + (unit ^ ((p >> 1) & 3))] = v;
-    }
-    // ---- 2. weight tile (contiguous on the host side) ----
-    for (int idx = tid; idx < WT_U; idx += 256) {
-      const int row = idx >> 2, unit = idx & 3;
-      wt[row * 4 + (unit ^ ((row >> 1) & 3))] = wsrc[(size_t)cc * WT_U + idx];
-    }
-    __syncthreads();
-    // ---- 3. taps: B fragments from the shifted patch, A fragments from the weight tile ----
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int kh = tap / KS, kw = tap % KS;
-      half8 bfrag[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int py = (wave * 2 + m) * S + kh;
-        const int px = (lane & 15) * S + kw;
-        const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
-        const int p = py * PWS + col;
-        uint4 u = patch[p * 4 + ((lane >> 4) ^ ((p >> 1) & 3))];
-        bfrag[m] = *reinterpret_cast<half8*>(&u);
-      }
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const int row = tap * 16 * NF + f * 16 + (lane & 15);
-        uint4 u = wt[row * 4 + ((lane >> 4) ^ ((row >> 1) & 3))];
-        half8 afrag = *reinterpret_cast<half8*>(&u);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-          acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag[m], acc[m][f], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue: lane = pixel (lane&15), 4 consecutive couts ((lane>>4)*4 + j) per fragment ----
-  const int ow = ow0 + (lane & 15);
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int oh = oh0 + wave * 2 + m;
-    if (oh >= a.Ho || ow >= a.Wo) continue;
-    const size_t opix = ((size_t)n * a.Ho + oh) * a.Wo + ow;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      const int c0 = co_tile * 16 * NF + f * 16 + (lane >> 4) * 4;
-      store_frag(a, acc[m][f], opix, c0, *reinterpret_cast<const float4*>(a.bias + c0));
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Deep-K 3x3 variant for the low-resolution half of the network (Cin >= 128 at 40x40 / 20x20): the
 // 8x16 spatial tile wastes up to half of every MFMA on a 20-wide map, so here a workgroup owns 64*MT
@@ -445,6 +349,127 @@ __device__ __forceinline__ void mma_taps(const uint4* patch, const uint4* wt_lan
         acc[m][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s][f], bf[s][m], acc[m][f], 0, 0, 0);
     if (tap + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, NF + MT, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, NF * MT, 0);
+  }
+}
+
+// Generic 3x3 kernel: one 8x16 output tile x one cout tile per workgroup, chunk by chunk (its LDS does not grow with
+// Cin).  What no persistent / flattened instantiation takes ends here - YOLOv8m's 96 / 192-channel stride-2 convs at
+// 160 / 80 / 40-wide maps.  Staging slots are computed once (the first build of this kernel redid the index arithmetic,
+// the bounds tests and a conditional load per unit and chunk, with nothing in flight behind the MFMAs: 200 TFLOP/s on
+// 96 -> 192 s2): a slot outside the image (zero padding) or past the patch loads element 0 and is zeroed / parked, so
+// the loads are unconditional and one chunk ahead of the taps that consume the previous one (mma_taps).
+template <int NF, int KS, int S>
+__global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+  static_assert(KS == 3, "the generic kernel serves 3x3 layers; 1x1 layers have k_conv1x1");
+  constexpr int PH = (kTH - 1) * S + KS;
+  constexpr int PW = (kTW - 1) * S + KS;
+  constexpr int PWH = (PW + 1) / 2;            // S == 2: columns stored de-interleaved (even | odd)
+  constexpr int PWS = (S == 2) ? 2 * PWH : PW;  // LDS row pitch in pixels
+  constexpr int TAPS = KS * KS;
+  constexpr int PAD = KS / 2;
+  constexpr int PATCH_U = PH * PWS * 4;  // uint4 units
+  constexpr int WT_U = TAPS * 16 * NF * 4;
+  constexpr int R = (PH * PW * 4 + 255) / 256;  // patch units staged per thread and chunk
+  constexpr int WREG = (WT_U + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* patch = reinterpret_cast<uint4*>(smem);
+  uint4* wt = patch + PATCH_U + 4;  // + one spare unit: where idle slots park their store
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bx = blockIdx.x;
+  const int tw = bx % a.tiles_w;
+  bx /= a.tiles_w;
+  const int th = bx % a.tiles_h;
+  const int n = bx / a.tiles_h;
+  const int oh0 = th * kTH, ow0 = tw * kTW;
+  const int ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+  const int co_tile = blockIdx.y;
+
+  int s_g[R], s_l[R];
+  unsigned s_ok = 0;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int idx = tid + 256 * j;
+    const int pix = idx >> 2, unit = idx & 3;
+    const int py = pix / PW, px = pix - py * PW;
+    const int ih = ih0 + py, iw = iw0 + px;
+    const bool in_patch = idx < PH * PW * 4;
+    const bool ok = in_patch && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+    const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
+    const int p = py * PWS + col;
+    s_g[j] = ok ? ((n * a.H + ih) * a.W + iw) * a.in_cs + unit * 8 : 0;
+    s_l[j] = in_patch ? p * 4 + (unit ^ ((p >> 1) & 3)) : PATCH_U;
+    s_ok |= (ok ? 1u : 0u) << j;
+  }
+  const uint4* wsrc = a.wgt + (size_t)co_tile * a.nchunks * WT_U + tid;
+  const bool cin_tail = (a.Cin & 31) != 0;
+  u32x4 sreg[R], wreg[WREG];
+  auto fetch = [&](int cc) {
+    const bool past = cin_tail && cc * 32 + (tid & 3) * 8 >= a.Cin;  // units past Cin: see k_conv3x3_flat
+    const __half* src = a.in + (past ? 0 : cc * 32);
+#pragma unroll
+    for (int j = 0; j < R; ++j) sreg[j] = *reinterpret_cast<const u32x4*>(src + (past ? 0 : s_g[j]));
+#pragma unroll
+    for (int j = 0; j < WREG; ++j)
+      if (WT_U % 256 == 0 || tid + j * 256 < WT_U) wreg[j] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)cc * WT_U + j * 256);
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      if (past || !((s_ok >> j) & 1)) sreg[j] = u32x4{0, 0, 0, 0};
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < R; ++j) *reinterpret_cast<u32x4*>(patch + s_l[j]) = sreg[j];
+#pragma unroll
+    for (int j = 0; j < WREG; ++j) {
+      const int idx = tid + j * 256;
+      const int row = idx >> 2, unit = idx & 3;
+      if (WT_U % 256 == 0 || idx < WT_U) *reinterpret_cast<u32x4*>(wt + row * 4 + (unit ^ ((row >> 1) & 3))) = wreg[j];
+    }
+  };
+  fetch(0);
+
+  int bpos[TAPS][2];
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int py = (wave * 2 + m) * S + tap / KS;
+      const int px = (lane & 15) * S + tap % KS;
+      const int col = (S == 2) ? ((px & 1) * PWH + (px >> 1)) : px;
+      const int p = py * PWS + col;
+      bpos[tap][m] = p * 4 + ((lane >> 4) ^ ((p >> 1) & 3));
+    }
+  const uint4* wt_lane = wt + (lane & 15) * 4 + ((lane >> 4) ^ ((lane >> 1) & 3));
+
+  float4v acc[2][NF];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  for (int cc = 0; cc < a.nchunks; ++cc) {
+    commit();
+    __syncthreads();
+    if (cc + 1 < a.nchunks) fetch(cc + 1);  // in flight behind the 9 taps below
+    __builtin_amdgcn_sched_barrier(0);
+    mma_taps<NF, 2>(patch, wt_lane, bpos, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane = pixel (lane&15), 4 consecutive couts ((lane>>4)*4 + j) per fragment ----
+  const int ow = ow0 + (lane & 15);
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int oh = oh0 + wave * 2 + m;
+    if (oh >= a.Ho || ow >= a.Wo) continue;
+    const size_t opix = ((size_t)n * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int c0 = co_tile * 16 * NF + f * 16 + (lane >> 4) * 4;
+      store_frag(a, acc[m][f], opix, c0, *reinterpret_cast<const float4*>(a.bias + c0));
+    }
   }
 }
 
@@ -1848,7 +1873,7 @@ int launch(const ConvArgs& a, int ntiles, hipStream_t stream) {
   constexpr int PH = (kTH - 1) * S + KS;
   constexpr int PW = (kTW - 1) * S + KS;
   constexpr int PWS = (S == 2) ? 2 * ((PW + 1) / 2) : PW;
-  constexpr size_t lds = (size_t)(PH * PWS * 4 + KS * KS * 16 * NF * 4) * 16;
+  constexpr size_t lds = (size_t)(PH * PWS * 4 + 4 + KS * KS * 16 * NF * 4) * 16;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_igemm<NF, KS, S>),
