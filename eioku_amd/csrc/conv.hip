@@ -1395,7 +1395,10 @@ constexpr size_t kStemChainLds = (size_t)(kSC_WT1 + kSC_WT2 + kSC_T + kSC_P1_U +
 
 // DECIM: the image region is a strided sampling of the source (FusedInput::step / off: 1080p -> 360 x 640 is step 3,
 // off 1): the 4 pixels of a group are 4 unaligned dword loads (3 bytes each + one ignored) instead of one dwordx3
-template <bool DECIM>
+// MODE 2: exact-1/2 sources (720p -> 360 x 640): cv2.resize swaps INTER_LINEAR for the 2x2 area average there; a group's
+// four pixels are 8 source pixels on each of two rows = 2 x 6 unaligned dwords, averaged (a + b + c + d + 2) >> 2 as K3
+// does.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st, FusedSrc fs, int total_tiles) {
   constexpr int GPR = 18;                 // 4-pixel groups per patch row: columns -1 .. 70
   constexpr int NG = kSX_H * GPR;         // 630
@@ -1427,7 +1430,9 @@ __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st
   }
   const int tiles_per_img = a.tiles_w * a.tiles_h;
   const float r_tpi = 1.0f / (float)tiles_per_img, r_tw = 1.0f / (float)a.tiles_w;
-  u32x4 graw[RG];  // !DECIM: 12 packed bytes in [0..2]; DECIM: one pixel per dword
+  constexpr bool DECIM = MODE == 1, HALF = MODE == 2;
+  u32x4 graw[RG];     // copy: 12 packed bytes in [0..2]; DECIM: one pixel per dword
+  unsigned gh[HALF ? RG : 1][12];  // HALF: 24 bytes of source row 2y, then 24 of row 2y + 1
   unsigned s_in = 0, s_img = 0;
   bool s_full = false;
   int nx_n = 0, nx_th = 0, nx_tw = 0;
@@ -1449,7 +1454,15 @@ __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st
       const bool img = in && (unsigned)y < (unsigned)fs.new_h && (unsigned)x < (unsigned)fs.new_w;
       s_in |= (in ? 1u : 0u) << j;
       s_img |= (img ? 1u : 0u) << j;
-      if (DECIM) {
+      if (HALF) {
+        const uint8_t* p = fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + 2 * y) * fs.src_w + 2 * x) * 3 : 0);
+        const size_t row = img ? (size_t)fs.src_w * 3 : 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          gh[j][i] = *reinterpret_cast<const u32_unaligned*>(p + 4 * i);
+          gh[j][6 + i] = *reinterpret_cast<const u32_unaligned*>(p + row + 4 * i);
+        }
+      } else if (DECIM) {
         const uint8_t* p = fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + y * fs.step + fs.off) * fs.src_w + x * fs.step + fs.off) * 3 : 0);
         const int ps = img ? fs.step * 3 : 0;
 #pragma unroll
@@ -1545,8 +1558,14 @@ __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st
           float v[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const int byte = DECIM ? 4 * i + c : 3 * i + c;
-            const float fb = (float)((graw[j][byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+            float fb;
+            if (HALF) {
+              auto bt = [&](int r, int b) { return (gh[j][6 * r + (b >> 2)] >> (8 * (b & 3))) & 0xffu; };
+              fb = (float)((bt(0, 6 * i + c) + bt(0, 6 * i + 3 + c) + bt(1, 6 * i + c) + bt(1, 6 * i + 3 + c) + 2u) >> 2);
+            } else {
+              const int byte = DECIM ? 4 * i + c : 3 * i + c;
+              fb = (float)((graw[j][byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+            }
             v[c] = (FULL || img) ? fb : 114.0f;
           }
           constexpr float k255 = 1.0f / 255.0f;
@@ -2142,8 +2161,8 @@ bool conv_stem_chain_ok(const ConvWeights& stem, const ConvWeights& c1, const Co
   // copy-mode letterbox whose rows and padding are 4-pixel aligned (12-byte group loads)
   // (a decimating copy loads pixel by pixel: no alignment of the source, but the groups still must not straddle the
   // image edge)
-  const bool src = f.bgr != nullptr && f.mode == 0 && f.left % 4 == 0 && f.new_w % 4 == 0 && W % 4 == 0 &&
-                   (f.step > 1 || (f.src_w % 4 == 0 && ((uintptr_t)f.bgr & 3) == 0));
+  const bool src = f.bgr != nullptr && (f.mode == 0 || f.mode == 2) && f.left % 4 == 0 && f.new_w % 4 == 0 && W % 4 == 0 &&
+                   (f.mode == 2 || f.step > 1 || (f.src_w % 4 == 0 && ((uintptr_t)f.bgr & 3) == 0));
   return shapes && src;
 }
 
@@ -2176,9 +2195,11 @@ int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, cons
   FusedSrc fs{f.bgr, f.src_h, f.src_w, f.new_h, f.new_w, f.top, f.left, f.step, f.off};
   static bool attr_set = false;
   if (!attr_set) {
-    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_stem_chain<false>),
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_stem_chain<0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStemChainLds));
-    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_stem_chain<true>),
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_stem_chain<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStemChainLds));
+    EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_stem_chain<2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStemChainLds));
     attr_set = true;
   }
@@ -2187,8 +2208,9 @@ int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, cons
   int bx = num_cus() * per_cu;
   if (bx > total) bx = total;
   prof_start(EIOKU_PROF_CONV, stream);
-  if (f.step > 1) hipLaunchKernelGGL(k_conv_stem_chain<true>, dim3((unsigned)bx), dim3(256), kStemChainLds, stream, a, st, fs, total);
-  else hipLaunchKernelGGL(k_conv_stem_chain<false>, dim3((unsigned)bx), dim3(256), kStemChainLds, stream, a, st, fs, total);
+  if (f.mode == 2) hipLaunchKernelGGL(k_conv_stem_chain<2>, dim3((unsigned)bx), dim3(256), kStemChainLds, stream, a, st, fs, total);
+  else if (f.step > 1) hipLaunchKernelGGL(k_conv_stem_chain<1>, dim3((unsigned)bx), dim3(256), kStemChainLds, stream, a, st, fs, total);
+  else hipLaunchKernelGGL(k_conv_stem_chain<0>, dim3((unsigned)bx), dim3(256), kStemChainLds, stream, a, st, fs, total);
   EIOKU_LAUNCH_CHECK();
   prof_stop(EIOKU_PROF_CONV, stream);
   return EIOKU_OK;
