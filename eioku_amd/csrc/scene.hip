@@ -704,9 +704,10 @@ int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t 
   }
   EIOKU_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint64_t) * 3 * n, stream));
 
-  // Q = 4 quads per thread, one frame ahead, 4 waves per SIMD: the r02 sweep (profiles/r02_scene_sweep.txt) moved K2 by
-  // < 4 % over quads 1..4 x frames in flight 1..4 x 4..16 workgroups per CU - it is bound by its ~30 integer VALU
-  // operations per pixel (the vector pipes are ~76 % busy), not by bytes in flight
+  // Q = 4 quads per thread, one frame ahead, five waves per SIMD: the r02 sweep (profiles/r02_scene_sweep.txt) moved K2 by
+  // < 4 % over quads 1..4 x frames in flight 1..4 x 4..16 workgroups per CU - it is bound by its ~22 integer VALU
+  // operations per pixel (PMC: the vector pipes are 87 % busy at 1080p), not by bytes in flight.  (Q = 2 for small
+  // frames - 64 x 640^2 offers only 800 workgroups to 1280 slots - measured the same: 31.4 us.)
   constexpr int Q = 4;
   const unsigned long long npix = (unsigned long long)h * w;
   unsigned long long nquads = npix >> 2;
