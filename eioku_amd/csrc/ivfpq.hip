@@ -181,8 +181,25 @@ __global__ __launch_bounds__(256) void k_ivfpq_tables(const float* __restrict__ 
   }
 }
 
-// grid (nq, nprobe); block 256.  probes: [nq][nprobe] list ids (-1 = none).
+// || q - c_l ||^2 of one (query, list) pair by a 256-thread workgroup: rq <- q - c_l (LDS, d floats), then thread t sums
+// rq[t]^2, rq[t + 256]^2, ... in that order, wave_reduce_add, (w0 + w1) + (w2 + w3).  The list-major path (k_term1)
+// reproduces exactly this order with one wave per pair so that both scans return the same bits.
+__device__ __forceinline__ float term1_block(const float* __restrict__ qrow, const float* __restrict__ crow, int d,
+                                             float* rq, float* s_part) {
+  const int tid = threadIdx.x;
+  for (int t = tid; t < d; t += 256) rq[t] = qrow[t] - crow[t];
+  __syncthreads();
+  float part = 0.f;
+  for (int t = tid; t < d; t += 256) part += rq[t] * rq[t];
+  part = wave_reduce_add(part);
+  if ((tid & 63) == 0) s_part[tid >> 6] = part;
+  __syncthreads();
+  return (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+// grid (nq, probes scanned <= nprobe); block 256.  probes: [nq][nprobe] list ids (-1 = none).
 // out: pd/pi [nprobe][nq][K]  (the [list][nq][k] layout k_topk_merge takes)
+// gate (optional): device word, the launch is a no-op when *gate == 0 (fallback of the list-major path)
 template <int K, int DSUB, bool PRE = false>
 __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q, int nq, int d, int m,
                                                     const long long* __restrict__ probes, int nprobe,
@@ -191,8 +208,10 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q,
                                                     const uint8_t* __restrict__ list_codes,
                                                     const long long* __restrict__ list_ids, float* __restrict__ pd,
                                                     long long* __restrict__ pi, const float* __restrict__ t2 = nullptr,
-                                                    const float* __restrict__ t3 = nullptr) {
+                                                    const float* __restrict__ t3 = nullptr,
+                                                    const int* __restrict__ gate = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lut[];  // [m][256], then merge area
+  if (gate && *gate == 0) return;  // uniform
   const int qi = blockIdx.x, pr = blockIdx.y, tid = threadIdx.x;
   const long long l = probes[(size_t)qi * nprobe + pr];
   SmallTop<K> top;
@@ -200,8 +219,6 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q,
   if (l >= 0) {
     // residual query r = q - coarse[l] once, in LDS (behind the LUT; the merge area reuses both later)
     float* rq = lut + (size_t)m * 256;
-    for (int t = tid; t < d; t += 256) rq[t] = q[(size_t)qi * d + t] - coarse[(size_t)l * d + t];
-    __syncthreads();
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int nent = m * 256;
     float term1 = 0.f;  // PRE: || q - c_l ||^2, added to every distance of the list
@@ -211,13 +228,10 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q,
       const f32x4* a = reinterpret_cast<const f32x4*>(t2 + (size_t)l * nent);
       const f32x4* b = reinterpret_cast<const f32x4*>(t3 + (size_t)qi * nent);
       for (int e4 = tid; e4 < nent / 4; e4 += 256) reinterpret_cast<f32x4*>(lut)[e4] = a[e4] + b[e4];
-      float part = 0.f;
-      for (int t = tid; t < d; t += 256) part += rq[t] * rq[t];
-      part = wave_reduce_add(part);
-      if ((tid & 63) == 0) s_part[tid >> 6] = part;
-      __syncthreads();
-      term1 = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+      term1 = term1_block(q + (size_t)qi * d, coarse + (size_t)l * d, d, rq, s_part);
     } else {
+    for (int t = tid; t < d; t += 256) rq[t] = q[(size_t)qi * d + t] - coarse[(size_t)l * d + t];
+    __syncthreads();
     // LUT[j][c] = || r_j - pq[j][c] ||^2 : 16-byte loads, LB entries in flight per thread (one entry per loop
     // iteration was 48 dependent L2 round trips per workgroup), same summation order as before
     constexpr int V4 = DSUB / 4, LB = 8;
@@ -480,7 +494,8 @@ namespace {
 int scan_launch(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe,
                 const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
                 const uint8_t* list_codes_dev, const long long* list_ids_dev, int k, float* pd_dev,
-                long long* pi_dev, const float* t2_dev, const float* t3_dev, void* stream_) {
+                long long* pi_dev, const float* t2_dev, const float* t3_dev, void* stream_, int nscan = 0,
+                const int* gate = nullptr) {
   EIOKU_REQUIRE_INIT();
   EIOKU_REQUIRE(q_dev && probes_dev && coarse_dev && pq_dev && offsets_dev && sizes_dev && pd_dev && pi_dev, "NULL buffer");
   EIOKU_REQUIRE(nq >= 0 && nprobe > 0 && k >= 1 && k <= 32 && d % m == 0, "bad argument");
@@ -494,7 +509,7 @@ int scan_launch(const float* q_dev, int nq, int d, int m, const long long* probe
   const size_t merge = (size_t)256 * K * 12;
   if (merge > lds) lds = merge;
   EIOKU_REQUIRE(lds <= 150 * 1024, "m=%d needs %zu bytes of LDS", m, lds);
-  dim3 grid((unsigned)nq, (unsigned)nprobe);
+  dim3 grid((unsigned)nq, (unsigned)(nscan > 0 ? nscan : nprobe));  // nscan: only the first probes of every query
   const bool pre = t2_dev != nullptr;
 #define EIOKU_SCAN1(K_, D_, P_)                                                                                \
   {                                                                                                            \
@@ -506,7 +521,7 @@ int scan_launch(const float* q_dev, int nq, int d, int m, const long long* probe
     }                                                                                                          \
     hipLaunchKernelGGL((k_ivfpq_scan<K_, D_, P_>), grid, dim3(256), lds, stream, q_dev, nq, d, m, probes_dev, nprobe, \
                        coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev, list_ids_dev, pd_dev, pi_dev, \
-                       t2_dev, t3_dev);                                                                        \
+                       t2_dev, t3_dev, gate);                                                                  \
   }
 #define EIOKU_SCAN(K_, D_) \
   if (pre) EIOKU_SCAN1(K_, D_, true) else EIOKU_SCAN1(K_, D_, false)
@@ -543,6 +558,748 @@ int eioku_ivfpq_scan_tables(const float* q_dev, int nq, int d, int m, const long
   EIOKU_REQUIRE(list_tables_dev && query_tables_dev, "NULL table");
   return scan_launch(q_dev, nq, d, m, probes_dev, nprobe, coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev,
                      list_ids_dev, k, pd_dev, pi_dev, list_tables_dev, query_tables_dev, stream_);
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// K10s: LIST-MAJOR ADC scan (round 3).
+//
+// The query-major scan above reads a list once per query that probes it: 1024 queries x 32 probes over 10 M x 48-byte
+// codes stream 15.6 GB of codes per search, and every (query, code) pair costs 48 LDS look-ups with random bank
+// conflicts.  Here the roles are swapped, exactly as in the flat index's scan path (knn.hip, k_l2_scan):
+//
+//   * the (query -> probes) relation is inverted into (list -> queries) by a counting sort per search;
+//   * a workgroup owns a SEGMENT of one list (NW x RT x 32 codes), DECODES it once into MFMA A operands held in
+//     registers - a lane's operand for k-step s is the 8 bf16 values of sub-quantiser 2s + half of its row's code, ONE
+//     16-byte gather from the 196 KB bf16 copy of the PQ codebook (L1/L2 resident) - and multiplies the segment with
+//     every 32-query tile of the list; the query tiles are gathered from the bf16 copy of the queries by LDS-DMA, one
+//     tile ahead.  Codes cross HBM once per search (0.48 GB at 10 M) and the products run on the matrix pipe;
+//   * ADC distance of (q, v in list l)  =  ||q - c_l||^2  +  ( ||p_v||^2 + 2 c_l.p_v )  -  2 q.p_v   (p_v = decoded
+//     residual).  The bracket is a per-code scalar stored with the index (hx = half of it), the first term a per-pair
+//     scalar, so the test  dist <= tau_q  becomes  q.p_v >= hx_v + 0.5 (t1 - tau_q)  on the MFMA accumulator;
+//   * the scan does not rank, it FILTERS with one bf16 product term and a rigorous margin
+//       |q.p - bf(q).bf(p)| <= (2^-7 + 2^-16) |q| |p|     (round-to-nearest bf16: unit roundoff 2^-8 per operand)
+//     plus an fp32 slack; tau_q = the k-th best EXACT distance over the query's nearest list (query-major kernel on
+//     probe 0: the k-th best of any subset bounds the k-th best of all).  Survivors are re-ranked with the query-major
+//     kernel's own fp32 arithmetic (same tables, same summation order): the (D, I) that come back are bit-identical to
+//     the query-major scan's.  A candidate list that overflows raises a flag that gates the query-major scan in.
+// =====================================================================================================================
+namespace {
+
+typedef unsigned u32x4k __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2k __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float f) {  // finite inputs
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// pq [m][256][8] fp32 -> pqh [m * 256] 16-byte units of 8 bf16 (round to nearest)
+__global__ __launch_bounds__(256) void k_pq_bf16(const float* __restrict__ pq, int nent, u32x4k* __restrict__ pqh) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= nent) return;
+  unsigned h[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) h[t] = bf16_rne_bits(pq[(size_t)e * 8 + t]);
+  pqh[e] = u32x4k{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+}
+
+// per stored code (grid = lists): hx = 0.5 * sum_j T2[l][j][c_j]  (fp32, j ascending) and the list's largest |p_v|^2
+__global__ __launch_bounds__(256) void k_list_aux(const uint8_t* __restrict__ codes, const int* __restrict__ offsets,
+                                                  const int* __restrict__ sizes, int m, const float* __restrict__ t2,
+                                                  const float* __restrict__ pq, float* __restrict__ hx,
+                                                  float* __restrict__ pmax2) {
+  const int l = blockIdx.x, off = offsets[l], sz = sizes[l];
+  const float* tl = t2 + (size_t)l * m * 256;
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < sz; i += 256) {
+    const uint8_t* code = codes + (size_t)(off + i) * m;
+    float s = 0.f, pn = 0.f;
+    for (int j = 0; j < m; ++j) {
+      const int e = j * 256 + code[j];
+      s += tl[e];
+      const float4 a = *reinterpret_cast<const float4*>(pq + (size_t)e * 8);
+      const float4 b = *reinterpret_cast<const float4*>(pq + (size_t)e * 8 + 4);
+      pn += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    }
+    hx[off + i] = 0.5f * s;
+    mx = fmaxf(mx, pn);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  __shared__ float s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) pmax2[l] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+}
+
+// queries -> bf16 rows + |q| (one wave per query)
+__global__ __launch_bounds__(256) void k_q_prep(const float* __restrict__ q, int nq, int d, unsigned short* __restrict__ qbf,
+                                                float* __restrict__ qn) {
+  const int qi = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (qi >= nq) return;
+  float s = 0.f;
+  for (int t = lane; t < d; t += 64) {
+    const float v = q[(size_t)qi * d + t];
+    qbf[(size_t)qi * d + t] = (unsigned short)bf16_rne_bits(v);
+    s += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) qn[qi] = sqrtf(s);
+}
+
+// t1[p] = || q - c_l ||^2 of pair p = q * nprobe + pr with term1_block's bits: a wave plays the four waves of that
+// workgroup (virtual thread v = lane + 64 w sums t = v, v + 256, ...; per-wave wave_reduce_add; (w0 + w1) + (w2 + w3))
+__global__ __launch_bounds__(256) void k_term1(const float* __restrict__ q, const float* __restrict__ coarse,
+                                               const long long* __restrict__ probes, int npairs, int nprobe, int d,
+                                               float* __restrict__ t1) {
+  const int p = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (p >= npairs) return;
+  const long long l = probes[p];
+  if (l < 0) {
+    if (lane == 0) t1[p] = 0.f;
+    return;
+  }
+  const float* qrow = q + (size_t)(p / nprobe) * d;
+  const float* crow = coarse + (size_t)l * d;
+  float w[4];
+#pragma unroll
+  for (int wv = 0; wv < 4; ++wv) {
+    float part = 0.f;
+    for (int t = lane + 64 * wv; t < d; t += 256) {
+      const float r = qrow[t] - crow[t];
+      part += r * r;
+    }
+    w[wv] = wave_reduce_add(part);
+  }
+  if (lane == 0) t1[p] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+
+// the list that bounds query q: its first probe that holds at least k codes (the k-th best of ANY k codes bounds the k-th
+// best of all; the nearest list itself may be empty or tiny on unbalanced indexes).  -1: no such list, no bound.
+__global__ __launch_bounds__(256) void k_tau_probe(const long long* __restrict__ probes, int nq, int nprobe,
+                                                   const int* __restrict__ sizes, int k, long long* __restrict__ tprobe) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  long long pick = -1;
+  for (int pr = 0; pr < nprobe; ++pr) {
+    const long long l = probes[(size_t)q * nprobe + pr];
+    if (l >= 0 && sizes[l] >= k) {
+      pick = l;
+      break;
+    }
+  }
+  tprobe[q] = pick;
+}
+
+// ---- inversion: (query -> probes) to (list -> queries) ----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_inv_count(const long long* __restrict__ probes, int npairs,
+                                                   const int* __restrict__ sizes, int* __restrict__ lcnt) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= npairs) return;
+  const long long l = probes[p];
+  if (l >= 0 && sizes[l] > 0) atomicAdd(&lcnt[l], 1);
+}
+
+// one workgroup: loff (slots, every list padded to whole 32-query tiles), woff (work items: segments of the lists that
+// have queries), totals; cursor zeroed
+__global__ __launch_bounds__(1024) void k_inv_scan(const int* __restrict__ lcnt, const int* __restrict__ sizes, int nlist,
+                                                   int seg, int* __restrict__ loff, int* __restrict__ woff,
+                                                   int* __restrict__ cursor, int* __restrict__ nwork) {
+  __shared__ int s_a[1024], s_b[1024];
+  const int tid = threadIdx.x;
+  const int per = (nlist + 1023) / 1024;
+  const int lo = tid * per, hi = min(nlist, lo + per);
+  int sa = 0, sb = 0;
+  for (int l = lo; l < hi; ++l) {
+    const int c = lcnt[l];
+    sa += (c + 31) & ~31;
+    sb += c > 0 ? (sizes[l] + seg - 1) / seg : 0;
+  }
+  s_a[tid] = sa;
+  s_b[tid] = sb;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int va = tid >= o ? s_a[tid - o] : 0, vb = tid >= o ? s_b[tid - o] : 0;
+    __syncthreads();
+    s_a[tid] += va;
+    s_b[tid] += vb;
+    __syncthreads();
+  }
+  int ra = s_a[tid] - sa, rb = s_b[tid] - sb;  // exclusive
+  for (int l = lo; l < hi; ++l) {
+    const int c = lcnt[l];
+    loff[l] = ra;
+    woff[l] = rb;
+    cursor[l] = 0;
+    ra += (c + 31) & ~31;
+    rb += c > 0 ? (sizes[l] + seg - 1) / seg : 0;
+  }
+  if (tid == 1023) {
+    loff[nlist] = s_a[1023];
+    woff[nlist] = s_b[1023];
+    *nwork = s_b[1023];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lq_fill(int* __restrict__ lq_q, float* __restrict__ lq_thr, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    lq_q[i] = 0;
+    lq_thr[i] = __builtin_inff();
+  }
+}
+
+// pair p -> a slot of its list; the slot's filter threshold: candidate  <=>  bf16 product >= hx_v + thr
+//   thr = 0.5 (t1 - tau) - [ 2^-7 (1 + 2^-9 + fp32 accumulation) |q| pmax_l  +  fp32 slack of the three scalar terms ]
+__global__ __launch_bounds__(256) void k_inv_scatter(const long long* __restrict__ probes, int npairs, int nprobe,
+                                                     const int* __restrict__ sizes, const int* __restrict__ loff,
+                                                     int* __restrict__ cursor, const float* __restrict__ t1,
+                                                     const float* __restrict__ taud, int K, int k,
+                                                     const float* __restrict__ qn, const float* __restrict__ pmax2,
+                                                     int* __restrict__ lq_q, int* __restrict__ lq_p,
+                                                     float* __restrict__ lq_thr) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= npairs) return;
+  const long long l = probes[p];
+  if (l < 0 || sizes[l] <= 0) return;
+  const int q = p / nprobe;
+  const int slot = loff[l] + atomicAdd(&cursor[l], 1);
+  const float tau = taud[(size_t)q * K + (k - 1)];  // FLT_MAX when the nearest list holds fewer than k codes
+  const float tt = t1[p], nq_ = qn[q], pm = sqrtf(pmax2[l]) * 1.000001f;
+  const float delta = 0.0078125f * 1.01f * nq_ * pm;
+  const float mag = tt + pm * pm + 2.f * (nq_ + sqrtf(tt)) * pm + 2.f * nq_ * pm;  // >= |t1| + |t2_v| + 2 |q.p_v|
+  lq_q[slot] = q;
+  lq_p[slot] = p;
+  lq_thr[slot] = tau >= 3.0e38f ? -__builtin_inff() : 0.5f * (tt - tau) - (delta + 2e-5f * mag);
+}
+
+struct LScanArgs {
+  const u32x4k* pqh;          // [m * 256]
+  const unsigned short* qbf;  // [nq][D]
+  const uint8_t* codes;       // list_codes [ntotal][m]
+  const float* hx;            // [ntotal]
+  const int* offsets;
+  const int* sizes;
+  const int* loff;            // [nlist + 1]
+  const int* woff;            // [nlist + 1]
+  const int* nwork;
+  const int* lq_q;
+  const float* lq_thr;
+  int nlist;
+  unsigned* wl;               // [gridDim.x][wl_cap][2]  (slot, code position)
+  int* wl_cnt;                // [gridDim.x]
+  int wl_cap;
+};
+
+// NS = d / 16 k-steps (dsub = 8: m = 2 NS); NW waves x RT 32-code tiles per workgroup and work item
+template <int NS, int NW, int RT>
+__global__ __launch_bounds__(NW * 64) void k_lscan(LScanArgs a) {
+  constexpr int PU = NS * 64, M = 2 * NS, CW = M / 4, D = NS * 16, SEG = NW * RT * 32;
+  constexpr int NDMA = (NS + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  u32x4k* qbuf = reinterpret_cast<u32x4k*>(dyn_smem);                       // [2][PU]
+  float* s_hx = reinterpret_cast<float*>(dyn_smem + (size_t)2 * PU * 16);   // [NW * RT * 32]
+  int* s_cnt = reinterpret_cast<int*>(s_hx + NW * RT * 32);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  if (tid == 0) *s_cnt = 0;
+  unsigned* const my_list = a.wl + (size_t)blockIdx.x * a.wl_cap * 2;
+  const int nwork = *a.nwork;
+
+  // one 32-query tile -> LDS in fragment order: DMA piece s is the 64 lanes' 16-byte B operands of k-step s, lane
+  // (col, half) fetching dims 16 s + 8 half + [0, 8) of ITS query's bf16 row.  Every wave issues NDMA pieces.
+  auto stage_q = [&](int qid, int buf) {
+    const unsigned char* row = reinterpret_cast<const unsigned char*>(a.qbf) + (size_t)qid * (D * 2) + half * 16;
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+      int s = j * NW + wave;
+      if (s >= NS) s = NS - 1;  // same bytes to the same place
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(row + s * 32), (lds_void_t*)(qbuf + (size_t)buf * PU + s * 64), 16, 0, 0);
+    }
+  };
+
+  for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
+    int lo = 0, hi = a.nlist;  // woff[lo] <= w < woff[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.woff[mid] <= w) lo = mid; else hi = mid;
+    }
+    const int l = lo, seg = w - a.woff[l];
+    const int off = a.offsets[l], sz = a.sizes[l];
+    const int slot0 = a.loff[l], nqt = (a.loff[l + 1] - slot0) >> 5;
+    __syncthreads();  // every wave is done with the previous item's query buffers
+
+    int qid = a.lq_q[slot0 + col];
+    float thr = a.lq_thr[slot0 + col];
+
+    // this wave's rows: code words, half table terms
+    u32x4k xh[RT][NS];
+    float hxmin[RT];
+    bool act[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int r0 = seg * SEG + (wave * RT + i) * 32;
+      act[i] = r0 < sz;
+      const int row = r0 + col;
+      const int rowc = row < sz ? row : sz - 1;
+      const unsigned* cp = reinterpret_cast<const unsigned*>(a.codes + (size_t)(off + rowc) * M);
+      unsigned cw[CW];
+      if constexpr (CW % 4 == 0) {
+#pragma unroll
+        for (int c = 0; c < CW / 4; ++c) {
+          const u32x4k v = *reinterpret_cast<const u32x4k*>(cp + 4 * c);
+          cw[4 * c] = v[0]; cw[4 * c + 1] = v[1]; cw[4 * c + 2] = v[2]; cw[4 * c + 3] = v[3];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CW / 2; ++c) {
+          const u32x2k v = *reinterpret_cast<const u32x2k*>(cp + 2 * c);
+          cw[2 * c] = v[0]; cw[2 * c + 1] = v[1];
+        }
+      }
+      float h = row < sz ? a.hx[off + row] : __builtin_inff();
+      if (half == 0) s_hx[(wave * RT + i) * 32 + col] = h;  // read back by this wave only
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) h = fminf(h, __shfl_xor(h, o, 64));
+      hxmin[i] = h;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const unsigned byte = (cw[s >> 1] >> (16 * (s & 1) + 8 * half)) & 0xFFu;
+        xh[i][s] = a.pqh[(2 * s + half) * 256 + byte];
+      }
+    }
+    stage_q(qid, 0);
+
+    for (int t = 0; t < nqt; ++t) {
+      int qid_n = 0;
+      float thr_n = 0.f;
+      if (t + 1 < nqt) {
+        qid_n = a.lq_q[slot0 + 32 * (t + 1) + col];
+        thr_n = a.lq_thr[slot0 + 32 * (t + 1) + col];
+      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of tile t (and the operands at t = 0)
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < nqt) stage_q(qid_n, (t + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4k* qb = qbuf + (size_t)(t & 1) * PU;
+      f32x16 acc[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      constexpr int PF = 2;
+      u32x4k bh[PF];
+#pragma unroll
+      for (int s = 0; s < PF; ++s) bh[s] = qb[s * 64 + lane];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const bf16x8 ch = __builtin_bit_cast(bf16x8, bh[s % PF]);
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xh[i][s]), ch, acc[i], 0, 0, 0);
+        if (s + PF < NS) bh[s % PF] = qb[(s + PF) * 64 + lane];
+      }
+      // filter (as k_l2_scan): tile maximum against the tile's smallest hx first, per row only where that passes
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const f32x16& c = acc[i];
+        float m01 = fmaxf(fmaxf(c[0], c[1]), c[2]), m23 = fmaxf(fmaxf(c[3], c[4]), c[5]);
+        float m45 = fmaxf(fmaxf(c[6], c[7]), c[8]), m67 = fmaxf(fmaxf(c[9], c[10]), c[11]);
+        float m89 = fmaxf(fmaxf(c[12], c[13]), c[14]);
+        const float mx = fmaxf(fmaxf(fmaxf(m01, m23), fmaxf(m45, m67)), fmaxf(m89, c[15]));
+        if (mx >= hxmin[i] + thr && act[i]) {
+          const int r0 = off + seg * SEG + (wave * RT + i) * 32;
+          int h4 = 4 * half;
+          asm volatile("" : "+v"(h4));
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 hx4 = *reinterpret_cast<const float4*>(s_hx + (wave * RT + i) * 32 + 8 * g + h4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float hxr = j == 0 ? hx4.x : (j == 1 ? hx4.y : (j == 2 ? hx4.z : hx4.w));
+              if (c[4 * g + j] >= hxr + thr) {
+                const int pos = atomicAdd(s_cnt, 1);  // LDS
+                if (pos < a.wl_cap) {
+                  my_list[2 * (size_t)pos] = (unsigned)(slot0 + 32 * t + col);
+                  my_list[2 * (size_t)pos + 1] = (unsigned)(r0 + 8 * g + j + h4);
+                }
+              }
+            }
+          }
+        }
+      }
+      qid = qid_n;
+      thr = thr_n;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) a.wl_cnt[blockIdx.x] = *s_cnt;
+}
+
+// workgroup lists -> per-query candidate lists
+__global__ __launch_bounds__(256) void k_lbin(const unsigned* __restrict__ wl, const int* __restrict__ wl_cnt, int wl_cap,
+                                              const int* __restrict__ lq_q, int* __restrict__ cand, int* __restrict__ cnt,
+                                              int cap, int* __restrict__ overflow) {
+  int c = wl_cnt[blockIdx.x];
+  if (c > wl_cap) {
+    if (threadIdx.x == 0) atomicOr(overflow, 1);
+    c = wl_cap;
+  }
+  const unsigned* list = wl + (size_t)blockIdx.x * wl_cap * 2;
+  for (int i = threadIdx.x; i < c; i += 256) {
+    const unsigned slot = list[2 * i], row = list[2 * i + 1];
+    const int qi = lq_q[slot];
+    const int pos = atomicAdd(cnt + qi, 1);
+    if (pos < cap) {
+      cand[((size_t)qi * cap + pos) * 2] = (int)slot;
+      cand[((size_t)qi * cap + pos) * 2 + 1] = (int)row;
+    }
+  }
+}
+
+// one workgroup per query: the candidates' ADC distances with the query-major kernel's arithmetic
+// (sum_j (T2[l][j][c] + T3[q][j][c]) in j order, + t1), then the k best by (distance, id)
+__global__ __launch_bounds__(256) void k_lrerank(const int* __restrict__ cand, const int* __restrict__ cnt, int cap, int m,
+                                                 const int* __restrict__ lq_p, const long long* __restrict__ probes,
+                                                 const float* __restrict__ t1, const float* __restrict__ t2,
+                                                 const float* __restrict__ t3, const uint8_t* __restrict__ codes,
+                                                 const long long* __restrict__ ids, int k, float* __restrict__ Dout,
+                                                 long long* __restrict__ Iout, int* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  const int nent = m * 256;
+  float* s_t3 = reinterpret_cast<float*>(dyn_smem);            // [m * 256]
+  long long* s_id = reinterpret_cast<long long*>(s_t3 + nent);  // [cap]
+  float* s_d = reinterpret_cast<float*>(s_id + cap);            // [cap]
+  __shared__ float s_bv[4];
+  __shared__ long long s_bi[4];
+  const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int c = cnt[qi];
+  if (tid == 0) {
+    atomicMax(overflow + 2, c);
+    atomicAdd(overflow + 3, c);
+  }
+  if (c > cap) {
+    if (tid == 0) atomicOr(overflow, 1);
+    c = cap;
+  }
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  for (int e4 = tid; e4 < nent / 4; e4 += 256)
+    reinterpret_cast<f32x4*>(s_t3)[e4] = reinterpret_cast<const f32x4*>(t3 + (size_t)qi * nent)[e4];
+  __syncthreads();
+  for (int j = tid; j < c; j += 256) {
+    const int slot = cand[((size_t)qi * cap + j) * 2], pos = cand[((size_t)qi * cap + j) * 2 + 1];
+    const int p = lq_p[slot];
+    const long long l = probes[p];
+    const float* tl = t2 + (size_t)l * nent;
+    const uint8_t* code = codes + (size_t)pos * m;
+    float s = 0.f;
+    for (int jj = 0; jj < m; ++jj) {
+      const int e = jj * 256 + code[jj];
+      s += tl[e] + s_t3[e];
+    }
+    s_d[j] = s + t1[p];
+    s_id[j] = ids[pos];
+  }
+  __syncthreads();
+  float lv = -__builtin_inff();
+  long long li = -1;
+  for (int r = 0; r < k; ++r) {
+    float bv = FLT_MAX;
+    long long bi = 0x7FFFFFFFFFFFFFFFll;
+    for (int j = tid; j < c; j += 256) {
+      const float v = s_d[j];
+      const long long i = s_id[j];
+      const bool after = v > lv || (v == lv && i > li);
+      if (after && (v < bv || (v == bv && i < bi))) {
+        bv = v;
+        bi = i;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const long long oi = __shfl_xor(bi, o, 64);
+      if (ov < bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      s_bv[wave] = bv;
+      s_bi[wave] = bi;
+    }
+    __syncthreads();
+    bv = s_bv[0];
+    bi = s_bi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (s_bv[w] < bv || (s_bv[w] == bv && s_bi[w] < bi)) {
+        bv = s_bv[w];
+        bi = s_bi[w];
+      }
+    __syncthreads();
+    const bool none = bi == 0x7FFFFFFFFFFFFFFFll;
+    if (tid == 0) {
+      Dout[(size_t)qi * k + r] = none ? FLT_MAX : bv;
+      Iout[(size_t)qi * k + r] = none ? -1 : bi;
+    }
+    lv = none ? FLT_MAX : bv;
+    li = none ? 0x7FFFFFFFFFFFFFFFll : bi;
+  }
+}
+
+// fallback merge (gated): the query-major scan's [nprobe][nq][K] partial lists -> (D, I); one wave per query
+__global__ __launch_bounds__(64) void k_probe_merge(const float* __restrict__ pd, const long long* __restrict__ pi, int nprobe,
+                                                    int nq, int K, int k, float* __restrict__ Dout,
+                                                    long long* __restrict__ Iout, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
+  const int qi = blockIdx.x, lane = threadIdx.x;
+  const int n = nprobe * K;
+  float lv = -__builtin_inff();
+  long long li = -1;
+  for (int r = 0; r < k; ++r) {
+    float bv = FLT_MAX;
+    long long bi = 0x7FFFFFFFFFFFFFFFll;
+    for (int e = lane; e < n; e += 64) {
+      const int pr = e / K, x = e - pr * K;
+      const float v = pd[((size_t)pr * nq + qi) * K + x];
+      const long long i = pi[((size_t)pr * nq + qi) * K + x];
+      if (i < 0) continue;
+      const bool after = v > lv || (v == lv && i > li);
+      if (after && (v < bv || (v == bv && i < bi))) {
+        bv = v;
+        bi = i;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const long long oi = __shfl_xor(bi, o, 64);
+      if (ov < bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    const bool none = bi == 0x7FFFFFFFFFFFFFFFll;
+    if (lane == 0) {
+      Dout[(size_t)qi * k + r] = none ? FLT_MAX : bv;
+      Iout[(size_t)qi * k + r] = none ? -1 : bi;
+    }
+    lv = none ? FLT_MAX : bv;
+    li = none ? 0x7FFFFFFFFFFFFFFFll : bi;
+  }
+}
+
+constexpr int kLNW = 8, kLRT = 2;  // workgroup = 8 waves x 2 tiles = 512 codes per work item
+
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct LWork {  // carve-up of the caller's workspace
+  size_t qbf, qn, t1, tprobe, pd, pi, zero0, lcnt, cnt, overflow, nwork, zero1, cursor, loff, woff, lq_q, lq_p, lq_thr, wl, wl_cnt, cand,
+      total;
+  int nslots, grid, wl_cap, cap, K;
+};
+
+LWork lwork(int nq, int d, int nprobe, int nlist, int k, int cap) {
+  LWork w;
+  const size_t npairs = (size_t)nq * nprobe;
+  w.K = k <= 16 ? 16 : 32;
+  w.cap = cap;
+  w.nslots = (int)(npairs + 31 * (npairs < (size_t)nlist ? npairs : (size_t)nlist));
+  w.grid = num_cus();
+  long long wl_cap = ((32ll << 20) / 8) / w.grid;
+  if (cap < 64) wl_cap = cap;  // tests shrink both kinds of list to force the overflow path
+  w.wl_cap = (int)wl_cap;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += al256(bytes); return at; };
+  w.qbf = take((size_t)nq * d * 2);
+  w.qn = take((size_t)nq * 4);
+  w.t1 = take(npairs * 4);
+  w.tprobe = take((size_t)nq * 8);
+  w.pd = take(npairs * w.K * 4);
+  w.pi = take(npairs * w.K * 8);
+  w.zero0 = o;
+  w.lcnt = take((size_t)nlist * 4);
+  w.cnt = take((size_t)nq * 4);
+  w.overflow = take(16);  // stats: overflow flag, work items, largest candidate list, candidates in all
+  w.nwork = w.overflow + 4;
+  w.zero1 = o;
+  w.cursor = take((size_t)nlist * 4);
+  w.loff = take((size_t)(nlist + 1) * 4);
+  w.woff = take((size_t)(nlist + 1) * 4);
+  w.lq_q = take((size_t)w.nslots * 4);
+  w.lq_p = take((size_t)w.nslots * 4);
+  w.lq_thr = take((size_t)w.nslots * 4);
+  w.wl = take((size_t)w.grid * w.wl_cap * 8);
+  w.wl_cnt = take((size_t)w.grid * 4);
+  w.cand = take((size_t)nq * cap * 8);
+  w.total = o;
+  return w;
+}
+
+template <int NS>
+int launch_lscan(const LScanArgs& a, int grid, hipStream_t stream) {
+  const size_t lds = (size_t)2 * NS * 64 * 16 + (size_t)kLNW * kLRT * 32 * 4 + 16;
+  static bool attr = false;
+  if (!attr) {
+    EIOKU_HIP_CHECK(hipFuncSetAttribute((const void*)k_lscan<NS, kLNW, kLRT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_lscan<NS, kLNW, kLRT>), dim3((unsigned)grid), dim3(kLNW * 64), lds, stream, a);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+bool lists_geometry_ok(int d, int m) { return m * 8 == d && (d == 64 || d == 128 || d == 256 || d == 384); }
+
+}  // namespace
+
+extern "C" {
+
+// Index-side tables of the list-major scan (once per pack / codebook change): pqh_out [m * 256] 16-byte units (the bf16
+// copy of the codebook), hx_out [ntotal] (half of each stored code's list-dependent scalar), pmax2_out [nlist].
+int eioku_ivfpq_lists_aux(const uint8_t* list_codes_dev, const int* offsets_dev, const int* sizes_dev, int nlist, int d, int m,
+                          const float* list_tables_dev, const float* pq_dev, void* pqh_out_dev, float* hx_out_dev,
+                          float* pmax2_out_dev, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(list_codes_dev && offsets_dev && sizes_dev && list_tables_dev && pq_dev && pqh_out_dev && hx_out_dev &&
+                    pmax2_out_dev && nlist > 0,
+                "bad argument");
+  EIOKU_REQUIRE(lists_geometry_ok(d, m), "list-major scan: d/m must be 8 and d in {64, 128, 256, 384} (got d=%d m=%d)", d, m);
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(k_pq_bf16, dim3((unsigned)(m * 256 + 255) / 256), dim3(256), 0, stream, pq_dev, m * 256, (u32x4k*)pqh_out_dev);
+  EIOKU_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_list_aux, dim3((unsigned)nlist), dim3(256), 0, stream, list_codes_dev, offsets_dev, sizes_dev, m,
+                     list_tables_dev, pq_dev, hx_out_dev, pmax2_out_dev);
+  EIOKU_LAUNCH_CHECK();
+  return EIOKU_OK;
+}
+
+// bytes of workspace eioku_ivfpq_search_lists needs (cand_cap: per-query candidate capacity, 0 = default 4096)
+long long eioku_ivfpq_lists_workspace(int nq, int d, int nprobe, int nlist, int k, int cand_cap) {
+  if (!initialised() || nq < 0 || nprobe <= 0 || nlist <= 0 || k < 1 || k > 32) return -1;
+  return (long long)lwork(nq, d, nprobe, nlist, k, cand_cap > 0 ? cand_cap : 4096).total;
+}
+
+// The whole search behind one call (all pointers DEVICE, asynchronous on `stream`): probes [nq][nprobe] from the coarse
+// quantiser, list_tables / query_tables as for eioku_ivfpq_scan_tables, pqh / hx / pmax2 from eioku_ivfpq_lists_aux.
+// D [nq][k], I [nq][k]: bit-identical to eioku_ivfpq_scan_tables + eioku_topk_merge_ex.  stats_out (optional, device,
+// 4 ints): overflow flag, work items, largest per-query candidate list, candidates of all queries.
+int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe, int nlist,
+                             const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
+                             const uint8_t* list_codes_dev, const long long* list_ids_dev, const float* list_tables_dev,
+                             const float* query_tables_dev, const void* pqh_dev, const float* hx_dev,
+                             const float* pmax2_dev, int k, int cand_cap, void* workspace_dev, long long workspace_bytes,
+                             float* D_dev, long long* I_dev, int* stats_out_dev, void* stream_) {
+  EIOKU_REQUIRE_INIT();
+  EIOKU_REQUIRE(q_dev && probes_dev && coarse_dev && pq_dev && offsets_dev && sizes_dev && list_codes_dev && list_ids_dev &&
+                    list_tables_dev && query_tables_dev && pqh_dev && hx_dev && pmax2_dev && workspace_dev && D_dev && I_dev,
+                "NULL buffer");
+  EIOKU_REQUIRE(nq >= 0 && nprobe > 0 && nlist > 0 && k >= 1 && k <= 32, "bad argument");
+  EIOKU_REQUIRE(lists_geometry_ok(d, m), "list-major scan: d/m must be 8 and d in {64, 128, 256, 384} (got d=%d m=%d)", d, m);
+  EIOKU_REQUIRE((long long)nq * nprobe < (1ll << 30), "nq x nprobe too large for one call");
+  if (nq == 0) return EIOKU_OK;
+  const int cap = cand_cap > 0 ? cand_cap : 4096;
+  const LWork w = lwork(nq, d, nprobe, nlist, k, cap);
+  EIOKU_REQUIRE(workspace_bytes >= (long long)w.total, "workspace: %lld bytes given, %zu needed", workspace_bytes, w.total);
+  const size_t rr_lds = (size_t)m * 256 * 4 + (size_t)cap * 12;
+  EIOKU_REQUIRE(rr_lds <= 150 * 1024, "cand_cap %d needs %zu bytes of LDS", cap, rr_lds);
+  hipStream_t stream = (hipStream_t)stream_;
+  unsigned char* ws = (unsigned char*)workspace_dev;
+  const int npairs = nq * nprobe;
+  unsigned short* qbf = (unsigned short*)(ws + w.qbf);
+  float* qn = (float*)(ws + w.qn);
+  float* t1 = (float*)(ws + w.t1);
+  float* pd = (float*)(ws + w.pd);
+  long long* pi = (long long*)(ws + w.pi);
+  int* lcnt = (int*)(ws + w.lcnt);
+  int* cnt = (int*)(ws + w.cnt);
+  int* overflow = (int*)(ws + w.overflow);
+  int* nwork = (int*)(ws + w.nwork);
+  int* cursor = (int*)(ws + w.cursor);
+  int* loff = (int*)(ws + w.loff);
+  int* woff = (int*)(ws + w.woff);
+  int* lq_q = (int*)(ws + w.lq_q);
+  int* lq_p = (int*)(ws + w.lq_p);
+  float* lq_thr = (float*)(ws + w.lq_thr);
+  unsigned* wl = (unsigned*)(ws + w.wl);
+  int* wl_cnt = (int*)(ws + w.wl_cnt);
+  int* cand = (int*)(ws + w.cand);
+
+  EIOKU_HIP_CHECK(hipMemsetAsync(ws + w.zero0, 0, w.zero1 - w.zero0, stream));
+  hipLaunchKernelGGL(k_q_prep, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q_dev, nq, d, qbf, qn);
+  hipLaunchKernelGGL(k_term1, dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, stream, q_dev, coarse_dev, probes_dev, npairs,
+                     nprobe, d, t1);
+  EIOKU_LAUNCH_CHECK();
+  // tau: the exact scan of one list per query - its nearest one with at least k codes (plane 0 of pd / pi)
+  long long* tprobe = (long long*)(ws + w.tprobe);
+  hipLaunchKernelGGL(k_tau_probe, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, probes_dev, nq, nprobe, sizes_dev, k,
+                     tprobe);
+  int rc = scan_launch(q_dev, nq, d, m, tprobe, 1, coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev,
+                       list_ids_dev, k, pd, pi, list_tables_dev, query_tables_dev, stream_, 1, nullptr);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_lq_fill, dim3((unsigned)std::min(1024, (w.nslots + 255) / 256)), dim3(256), 0, stream, lq_q, lq_thr, w.nslots);
+  hipLaunchKernelGGL(k_inv_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, stream, probes_dev, npairs, sizes_dev, lcnt);
+  hipLaunchKernelGGL(k_inv_scan, dim3(1), dim3(1024), 0, stream, lcnt, sizes_dev, nlist, kLNW * kLRT * 32, loff, woff, cursor, nwork);
+  hipLaunchKernelGGL(k_inv_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, stream, probes_dev, npairs, nprobe,
+                     sizes_dev, loff, cursor, t1, pd, w.K, k, qn, pmax2_dev, lq_q, lq_p, lq_thr);
+  EIOKU_LAUNCH_CHECK();
+  LScanArgs a;
+  a.pqh = (const u32x4k*)pqh_dev;
+  a.qbf = qbf;
+  a.codes = list_codes_dev;
+  a.hx = hx_dev;
+  a.offsets = offsets_dev;
+  a.sizes = sizes_dev;
+  a.loff = loff;
+  a.woff = woff;
+  a.nwork = nwork;
+  a.lq_q = lq_q;
+  a.lq_thr = lq_thr;
+  a.nlist = nlist;
+  a.wl = wl;
+  a.wl_cnt = wl_cnt;
+  a.wl_cap = w.wl_cap;
+  switch (d / 16) {
+    case 4: rc = launch_lscan<4>(a, w.grid, stream); break;
+    case 8: rc = launch_lscan<8>(a, w.grid, stream); break;
+    case 16: rc = launch_lscan<16>(a, w.grid, stream); break;
+    default: rc = launch_lscan<24>(a, w.grid, stream); break;
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_lbin, dim3((unsigned)w.grid), dim3(256), 0, stream, wl, wl_cnt, w.wl_cap, lq_q, cand, cnt, cap, overflow);
+  {
+    static size_t attr_lds = 0;
+    if (rr_lds > attr_lds) {
+      EIOKU_HIP_CHECK(hipFuncSetAttribute((const void*)k_lrerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rr_lds));
+      attr_lds = rr_lds;
+    }
+  }
+  hipLaunchKernelGGL(k_lrerank, dim3((unsigned)nq), dim3(256), rr_lds, stream, cand, cnt, cap, m, lq_p, probes_dev, t1,
+                     list_tables_dev, query_tables_dev, list_codes_dev, list_ids_dev, k, D_dev, I_dev, overflow);
+  EIOKU_LAUNCH_CHECK();
+  // a candidate list overflowed (no contrast in the data, or a nearest list with fewer than k codes): the query-major
+  // scan redoes the search; both launches are no-ops otherwise
+  rc = scan_launch(q_dev, nq, d, m, probes_dev, nprobe, coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev,
+                   list_ids_dev, k, pd, pi, list_tables_dev, query_tables_dev, stream_, 0, overflow);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)nq), dim3(64), 0, stream, pd, pi, nprobe, nq, w.K, k, D_dev, I_dev, overflow);
+  EIOKU_LAUNCH_CHECK();
+  if (stats_out_dev) EIOKU_HIP_CHECK(hipMemcpyAsync(stats_out_dev, overflow, 16, hipMemcpyDeviceToDevice, stream));
+  return EIOKU_OK;
 }
 
 }  // extern "C"

@@ -138,6 +138,14 @@ class IndexIVFPQ:
         self._packed = None
         self.use_precomputed_table = True   # FAISS' IndexIVFPQ.use_precomputed_table; False = tables from the codebook per (query, list)
         self._list_tables = None
+        # "lists": the list-major scan (codes cross HBM once per search, MFMA filter + exact re-rank; same (D, I) bits as
+        # "queries"); "queries": one workgroup per (query, probe).  "lists" needs d/m = 8, d in {64, 128, 256, 384} and the
+        # precomputed tables; other geometries always take "queries".
+        self.scan_mode = "lists"
+        self.cand_cap = 4096                # per-query candidate capacity of the list-major filter (overflow -> query-major redo)
+        self._aux = None                    # (pqh, hx, pmax2) of the current pack
+        self._ws = None
+        self.last_stats = None              # device int32[4] after a list-major search: overflow flag, work items, largest candidate list, candidates in all
         self.allreduce_calls = 0
 
     # ---- training ------------------------------------------------------------------------------
@@ -200,7 +208,10 @@ class IndexIVFPQ:
             pq = torch.stack([ops.finalize(packed[j], pq[j].contiguous()) for j in range(self.m)]).contiguous()
         self.pq = pq
         self._list_tables = None
+        self._aux = None
         if self._lib is not None:
+            if self._quantizer is not None:
+                self._quantizer.close()
             self._quantizer = IndexFlatL2(self.d)
             self._quantizer.attach(self.coarse)
         self.is_trained = True
@@ -212,6 +223,7 @@ class IndexIVFPQ:
         self.coarse = torch.as_tensor(coarse, dtype=torch.float32).to(self.device).contiguous()
         self.pq = torch.as_tensor(pq, dtype=torch.float32).to(self.device).contiguous()
         self._list_tables = None
+        self._aux = None
         if self._quantizer is not None:
             self._quantizer.close()
         self._quantizer = IndexFlatL2(self.d)
@@ -236,6 +248,7 @@ class IndexIVFPQ:
         self._pending.append((lst, codes, self.ntotal))
         self.ntotal += n
         self._packed = None
+        self._aux = None
 
     def _pack(self):
         """Counting sort of everything added so far into contiguous inverted lists."""
@@ -270,8 +283,11 @@ class IndexIVFPQ:
         _, probes = self._quantizer.search_many(q, nprobe)  # nprobe > 32: chained rounds of 32 (search_after)
         probes = probes.contiguous()
         K = 16 if k <= 16 else 32
-        pd = torch.empty((nprobe, nq, K), dtype=torch.float32, device=self.device)
-        pi = torch.empty((nprobe, nq, K), dtype=torch.int64, device=self.device)
+        lists = (self.scan_mode == "lists" and self.use_precomputed_table and self.dsub == 8
+                 and self.d in (64, 128, 256, 384) and self.ntotal > 0)
+        if not lists:
+            pd = torch.empty((nprobe, nq, K), dtype=torch.float32, device=self.device)
+            pi = torch.empty((nprobe, nq, K), dtype=torch.int64, device=self.device)
         if self.use_precomputed_table:
             # FAISS' decomposition: the per-list half of every look-up table is part of the index (nlist x m x 1 KB, built
             # on the first search after the codebooks change), the per-query half is built once per search
@@ -282,6 +298,8 @@ class IndexIVFPQ:
             qt = torch.empty((nq, self.m, 256), dtype=torch.float32, device=self.device)
             _lib.check(self._lib.eioku_ivfpq_tables(ptr(q), nq, self.d, self.m, ptr(self.pq), 0.0, -2.0, ptr(qt),
                                                     current_stream(q)), "eioku_ivfpq_tables")
+            if lists:
+                return self._search_lists(q, k, probes, nprobe, qt, offsets, sizes, list_codes, list_ids)
             _lib.check(self._lib.eioku_ivfpq_scan_tables(ptr(q), nq, self.d, self.m, ptr(probes), nprobe, ptr(self.coarse),
                                                          ptr(self.pq), ptr(offsets), ptr(sizes), ptr(list_codes), ptr(list_ids),
                                                          ptr(self._list_tables), ptr(qt), k, ptr(pd), ptr(pi),
@@ -294,4 +312,34 @@ class IndexIVFPQ:
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         _lib.check(self._lib.eioku_topk_merge_ex(ptr(pd), ptr(pi), nprobe, nq, K, k, ptr(D), ptr(I), current_stream(q)),
                    "eioku_topk_merge_ex")
+        return D, I
+
+    def _search_lists(self, q, k, probes, nprobe, qt, offsets, sizes, list_codes, list_ids):
+        """The list-major scan (``eioku_ivfpq_search_lists``): one C call enqueues the whole search."""
+        import torch
+
+        nq = int(q.shape[0])
+        if self._aux is None:
+            pqh = torch.empty((self.m * 256, 4), dtype=torch.int32, device=self.device)
+            hx = torch.empty((max(self.ntotal, 1),), dtype=torch.float32, device=self.device)
+            pmax2 = torch.empty((self.nlist,), dtype=torch.float32, device=self.device)
+            _lib.check(self._lib.eioku_ivfpq_lists_aux(ptr(list_codes), ptr(offsets), ptr(sizes), self.nlist, self.d, self.m,
+                                                       ptr(self._list_tables), ptr(self.pq), ptr(pqh), ptr(hx), ptr(pmax2),
+                                                       current_stream(q)), "eioku_ivfpq_lists_aux")
+            self._aux = (pqh, hx, pmax2)
+        pqh, hx, pmax2 = self._aux
+        need = int(self._lib.eioku_ivfpq_lists_workspace(nq, self.d, nprobe, self.nlist, k, self.cand_cap))
+        if need < 0:
+            raise _lib.EiokuHipError("eioku_ivfpq_lists_workspace: bad argument")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        stats = torch.zeros((4,), dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.eioku_ivfpq_search_lists(ptr(q), nq, self.d, self.m, ptr(probes), nprobe, self.nlist, ptr(self.coarse),
+                                                      ptr(self.pq), ptr(offsets), ptr(sizes), ptr(list_codes), ptr(list_ids),
+                                                      ptr(self._list_tables), ptr(qt), ptr(pqh), ptr(hx), ptr(pmax2), k,
+                                                      self.cand_cap, ptr(self._ws), self._ws.numel(), ptr(D), ptr(I), ptr(stats),
+                                                      current_stream(q)), "eioku_ivfpq_search_lists")
+        self.last_stats = stats
         return D, I

@@ -317,6 +317,30 @@ int eioku_ivfpq_scan_tables(const float* q_dev, int nq, int d, int m, const long
                             const float* list_tables_dev, const float* query_tables_dev, int k, float* pd_dev,
                             long long* pi_dev, void* stream);
 
+/* List-major form of the scan (round 3; d/m = 8, d in {64, 128, 256, 384}): the (query -> probes) relation is inverted per
+ * search, a workgroup decodes a segment of ONE list once into bf16 MFMA operands and multiplies it with every query that
+ * probes the list; the products only FILTER (rigorous bf16 margin against the k-th exact distance of the query's
+ * nearest list), survivors are re-ranked with eioku_ivfpq_scan_tables' own fp32 arithmetic: (D, I) are bit-identical
+ * to eioku_ivfpq_scan_tables + eioku_topk_merge_ex, codes cross HBM once per search instead of once per (query, probe).
+ *   eioku_ivfpq_lists_aux       : index-side tables, once per pack: pqh_out [m * 256 * 16 B] (bf16 codebook),
+ *                                 hx_out [ntotal] floats, pmax2_out [nlist] floats.
+ *   eioku_ivfpq_lists_workspace : bytes of device workspace one search of nq queries needs (-1: bad argument).
+ *   eioku_ivfpq_search_lists    : the whole search; probes [nq][nprobe] from the coarse quantiser; cand_cap = per-query
+ *                                 candidate capacity (0: 4096); a list that overflows gates the query-major scan in
+ *                                 (same results, slower).  stats_out (optional, device, 4 ints): overflow flag, work items,
+ *                                 largest per-query candidate list, candidates of all queries.
+ * Replaces: FAISS IndexIVFPQ::search as planned by /root/reference/.kiro/specs/semantic-video-search/design.md:35-40,1105-1113. */
+int eioku_ivfpq_lists_aux(const uint8_t* list_codes_dev, const int* offsets_dev, const int* sizes_dev, int nlist, int d, int m,
+                          const float* list_tables_dev, const float* pq_dev, void* pqh_out_dev, float* hx_out_dev,
+                          float* pmax2_out_dev, void* stream);
+long long eioku_ivfpq_lists_workspace(int nq, int d, int nprobe, int nlist, int k, int cand_cap);
+int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe, int nlist,
+                             const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
+                             const uint8_t* list_codes_dev, const long long* list_ids_dev, const float* list_tables_dev,
+                             const float* query_tables_dev, const void* pqh_dev, const float* hx_dev,
+                             const float* pmax2_dev, int k, int cand_cap, void* workspace_dev, long long workspace_bytes,
+                             float* D_dev, long long* I_dev, int* stats_out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -220,3 +220,79 @@ def test_cfg5_geometry_nlist4096_m48_and_sharded_wrapper(gpu):
     _lib.check(_lib.load().eioku_kmeans_update(ptr(xd[:5000].contiguous()), 5000, d, ptr(a), nlist, ptr(c1), None, None), "kmeans_update")
     c2 = ops.finalize(ops.accumulate(xd[:5000].contiguous(), a, nlist), ix.coarse.clone())
     assert torch.equal(c1, c2)
+
+
+def _both_modes(ix, q, k):
+    ix.scan_mode = "queries"
+    Dq, Iq = ix.search(q, k)
+    ix.scan_mode = "lists"
+    Dl, Il = ix.search(q, k)
+    return Dq, Iq, Dl, Il
+
+
+@pytest.mark.parametrize("d,m,nlist,n,nq,nprobe,k", [
+    (64, 8, 16, 6000, 40, 4, 10),
+    (128, 16, 50, 30000, 100, 8, 10),
+    (384, 48, 64, 12000, 33, 8, 10),
+    (384, 48, 300, 60000, 257, 32, 20),   # k > 16: the 32-wide partial lists; ragged query tiles
+    (256, 32, 40, 9000, 5, 40, 1),        # every list probed, k = 1
+])
+def test_list_major_scan_is_bit_identical_to_query_major(gpu, d, m, nlist, n, nq, nprobe, k):
+    """Round 3: the list-major scan filters with bf16 MFMA products and re-ranks the survivors with
+    the query-major kernel's fp32 arithmetic, so distances AND ids must be the query-major scan's, bit for bit - on
+    unbalanced lists (clustered rows), lists without rows, queries that are database rows (distance ~ 0 candidates)
+    and far-away queries alike."""
+    import torch
+
+    x = clustered(7, n, d, ncl=max(8, nlist // 2), spread=0.2)
+    ix = ivfpq.IndexIVFPQ(d, nlist, m)
+    ix.train(x[: max(nlist * 40, 3000)])
+    ix.add(x[: n // 3])
+    ix.add(x[n // 3:])
+    ix.nprobe = nprobe
+    rng = np.random.default_rng(8)
+    q = clustered(9, nq, d, ncl=max(8, nlist // 2), spread=0.2)
+    q[: nq // 3] = x[rng.integers(0, n, nq // 3)]           # exact copies of rows
+    q[-1] = -q[-1]                                           # far from everything
+    Dq, Iq, Dl, Il = _both_modes(ix, q, k)
+    assert int(ix.last_stats[0]) == 0, "candidate lists overflowed on ordinary data"
+    assert torch.equal(Iq, Il)
+    assert torch.equal(Dq, Dl)
+    assert int((Iq >= 0).sum()) > 0
+    ix._quantizer.close()
+
+
+def test_list_major_overflow_falls_back_to_the_query_major_scan(gpu):
+    """A candidate capacity of 8 per query (and per workgroup list) cannot hold the survivors: the overflow flag must be
+    raised and the gated query-major launches must deliver the same (D, I)."""
+    import torch
+
+    d, m, nlist = 64, 8, 16
+    x = clustered(1, 8000, d)
+    ix = ivfpq.IndexIVFPQ(d, nlist, m)
+    ix.train(x[:4000])
+    ix.add(x)
+    ix.nprobe = 8
+    q = clustered(2, 50, d)
+    ix.scan_mode = "queries"
+    Dq, Iq = ix.search(q, 10)
+    ix.scan_mode = "lists"
+    ix.cand_cap = 8
+    Dl, Il = ix.search(q, 10)
+    assert int(ix.last_stats[0]) == 1
+    assert torch.equal(Iq, Il) and torch.equal(Dq, Dl)
+    ix.cand_cap = 2048
+    Dl, Il = ix.search(q, 10)
+    assert int(ix.last_stats[0]) == 0
+    assert torch.equal(Iq, Il) and torch.equal(Dq, Dl)
+    # an index none of whose lists holds k rows has no bound: everything is a candidate, still identical (fewer than k results)
+    tiny = ivfpq.IndexIVFPQ(d, nlist, m)
+    tiny.set_codebooks(ix.coarse, ix.pq)
+    tiny.add(x[:20])
+    tiny.nprobe = 16
+    Dq, Iq, Dl, Il = _both_modes(tiny, q, 10)
+    assert torch.equal(Iq, Il) and torch.equal(Dq, Dl)
+    Dq, Iq, Dl, Il = _both_modes(tiny, q, 32)
+    assert torch.equal(Iq, Il) and torch.equal(Dq, Dl) and int((Il < 0).sum()) > 0
+    ix._quantizer.close()
+    tiny._quantizer.close()
