@@ -117,8 +117,8 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "eioku_ivfpq_lists_aux": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "eioku_ivfpq_lists_workspace": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "eioku_ivfpq_search_lists": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+    "eioku_ivfpq_lists_workspace": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int]),
+    "eioku_ivfpq_search_lists": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -17,6 +17,7 @@
 #include "common.h"
 
 #include <cfloat>
+#include <cstdlib>
 
 using namespace eioku;
 
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q,
                                                     const long long* __restrict__ list_ids, float* __restrict__ pd,
                                                     long long* __restrict__ pi, const float* __restrict__ t2 = nullptr,
                                                     const float* __restrict__ t3 = nullptr,
-                                                    const int* __restrict__ gate = nullptr) {
+                                                    const int* __restrict__ gate = nullptr, int max_rows = 0) {
   extern __shared__ __attribute__((aligned(16))) float lut[];  // [m][256], then merge area
   if (gate && *gate == 0) return;  // uniform
   const int qi = blockIdx.x, pr = blockIdx.y, tid = threadIdx.x;
@@ -263,7 +264,8 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q,
     }
     }
     __syncthreads();
-    const int off = offsets[l], sz = sizes[l];
+    // max_rows > 0: only the list's first rows (the bound of the list-major path: the k-th best of a subset)
+    const int off = offsets[l], sz = max_rows > 0 && sizes[l] > max_rows ? max_rows : sizes[l];
     const bool vec_codes = (m & 15) == 0 && m <= 64 && ((size_t)off * m & 15) == 0;  // rows stay 16-byte aligned
     if (vec_codes) {
       // codes and id of the NEXT vector are in flight while the current one is looked up
@@ -495,7 +497,7 @@ int scan_launch(const float* q_dev, int nq, int d, int m, const long long* probe
                 const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
                 const uint8_t* list_codes_dev, const long long* list_ids_dev, int k, float* pd_dev,
                 long long* pi_dev, const float* t2_dev, const float* t3_dev, void* stream_, int nscan = 0,
-                const int* gate = nullptr) {
+                const int* gate = nullptr, int max_rows = 0) {
   EIOKU_REQUIRE_INIT();
   EIOKU_REQUIRE(q_dev && probes_dev && coarse_dev && pq_dev && offsets_dev && sizes_dev && pd_dev && pi_dev, "NULL buffer");
   EIOKU_REQUIRE(nq >= 0 && nprobe > 0 && k >= 1 && k <= 32 && d % m == 0, "bad argument");
@@ -521,7 +523,7 @@ int scan_launch(const float* q_dev, int nq, int d, int m, const long long* probe
     }                                                                                                          \
     hipLaunchKernelGGL((k_ivfpq_scan<K_, D_, P_>), grid, dim3(256), lds, stream, q_dev, nq, d, m, probes_dev, nprobe, \
                        coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev, list_ids_dev, pd_dev, pi_dev, \
-                       t2_dev, t3_dev, gate);                                                                  \
+                       t2_dev, t3_dev, gate, max_rows);                                                        \
   }
 #define EIOKU_SCAN(K_, D_) \
   if (pre) EIOKU_SCAN1(K_, D_, true) else EIOKU_SCAN1(K_, D_, false)
@@ -749,6 +751,22 @@ __global__ __launch_bounds__(1024) void k_inv_scan(const int* __restrict__ lcnt,
   }
 }
 
+// work item w -> {first code position, codes in the segment, first slot of the list, query tiles of the list}: the scan
+// reads one 16-byte descriptor per item (prefetched an item ahead) instead of searching the prefix sums itself
+__global__ __launch_bounds__(256) void k_inv_items(const int* __restrict__ woff, const int* __restrict__ loff,
+                                                   const int* __restrict__ offsets, const int* __restrict__ sizes, int nlist,
+                                                   int seg, int max_items, int4* __restrict__ items) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= woff[nlist] || w >= max_items) return;
+  int lo = 0, hi = nlist;  // woff[lo] <= w < woff[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (woff[mid] <= w) lo = mid; else hi = mid;
+  }
+  const int r0 = (w - woff[lo]) * seg;
+  items[w] = make_int4(offsets[lo] + r0, min(seg, sizes[lo] - r0), loff[lo], (loff[lo + 1] - loff[lo]) >> 5);
+}
+
 __global__ __launch_bounds__(256) void k_lq_fill(int* __restrict__ lq_q, float* __restrict__ lq_thr, int n) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     lq_q[i] = 0;
@@ -785,23 +803,20 @@ struct LScanArgs {
   const unsigned short* qbf;  // [nq][D]
   const uint8_t* codes;       // list_codes [ntotal][m]
   const float* hx;            // [ntotal]
-  const int* offsets;
-  const int* sizes;
-  const int* loff;            // [nlist + 1]
-  const int* woff;            // [nlist + 1]
+  const int4* items;          // [nwork] {first code position, codes, first slot, query tiles}
   const int* nwork;
   const int* lq_q;
   const float* lq_thr;
-  int nlist;
   unsigned* wl;               // [gridDim.x][wl_cap][2]  (slot, code position)
   int* wl_cnt;                // [gridDim.x]
   int wl_cap;
+  int ablate;                 // measurement builds only (EIOKU_LSCAN_ABLATE): 1 = no table gathers, 2 = no products
 };
 
 // NS = d / 16 k-steps (dsub = 8: m = 2 NS); NW waves x RT 32-code tiles per workgroup and work item
 template <int NS, int NW, int RT>
 __global__ __launch_bounds__(NW * 64) void k_lscan(LScanArgs a) {
-  constexpr int PU = NS * 64, M = 2 * NS, CW = M / 4, D = NS * 16, SEG = NW * RT * 32;
+  constexpr int PU = NS * 64, M = 2 * NS, CW = M / 4, D = NS * 16;
   constexpr int NDMA = (NS + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   u32x4k* qbuf = reinterpret_cast<u32x4k*>(dyn_smem);                       // [2][PU]
@@ -827,19 +842,21 @@ __global__ __launch_bounds__(NW * 64) void k_lscan(LScanArgs a) {
     }
   };
 
+  int4 it_n = blockIdx.x < nwork ? a.items[blockIdx.x] : make_int4(0, 0, 0, 0);
   for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
-    int lo = 0, hi = a.nlist;  // woff[lo] <= w < woff[hi]
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (a.woff[mid] <= w) lo = mid; else hi = mid;
-    }
-    const int l = lo, seg = w - a.woff[l];
-    const int off = a.offsets[l], sz = a.sizes[l];
-    const int slot0 = a.loff[l], nqt = (a.loff[l + 1] - slot0) >> 5;
+    const int4 it = it_n;
+    if (w + (int)gridDim.x < nwork) it_n = a.items[w + gridDim.x];
+    const int pos0 = it.x, nrows = it.y, slot0 = it.z, nqt = it.w;
     __syncthreads();  // every wave is done with the previous item's query buffers
 
     int qid = a.lq_q[slot0 + col];
     float thr = a.lq_thr[slot0 + col];
+    int qid1 = 0;      // tile 1's queries (tile t + 1 in the loop below: loaded a whole tile before they are needed)
+    float thr1 = 0.f;
+    if (nqt > 1) {
+      qid1 = a.lq_q[slot0 + 32 + col];
+      thr1 = a.lq_thr[slot0 + 32 + col];
+    }
 
     // this wave's rows: code words, half table terms
     u32x4k xh[RT][NS];
@@ -847,11 +864,11 @@ __global__ __launch_bounds__(NW * 64) void k_lscan(LScanArgs a) {
     bool act[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
-      const int r0 = seg * SEG + (wave * RT + i) * 32;
-      act[i] = r0 < sz;
+      const int r0 = (wave * RT + i) * 32;
+      act[i] = r0 < nrows;
       const int row = r0 + col;
-      const int rowc = row < sz ? row : sz - 1;
-      const unsigned* cp = reinterpret_cast<const unsigned*>(a.codes + (size_t)(off + rowc) * M);
+      const int rowc = row < nrows ? row : nrows - 1;
+      const unsigned* cp = reinterpret_cast<const unsigned*>(a.codes + (size_t)(pos0 + rowc) * M);
       unsigned cw[CW];
       if constexpr (CW % 4 == 0) {
 #pragma unroll
@@ -866,33 +883,33 @@ __global__ __launch_bounds__(NW * 64) void k_lscan(LScanArgs a) {
           cw[2 * c] = v[0]; cw[2 * c + 1] = v[1];
         }
       }
-      float h = row < sz ? a.hx[off + row] : __builtin_inff();
+      float h = row < nrows ? a.hx[pos0 + row] : __builtin_inff();
       if (half == 0) s_hx[(wave * RT + i) * 32 + col] = h;  // read back by this wave only
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) h = fminf(h, __shfl_xor(h, o, 64));
       hxmin[i] = h;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const unsigned byte = (cw[s >> 1] >> (16 * (s & 1) + 8 * half)) & 0xFFu;
+        const unsigned byte = (a.ablate & 1) ? (unsigned)col : (cw[s >> 1] >> (16 * (s & 1) + 8 * half)) & 0xFFu;
         xh[i][s] = a.pqh[(2 * s + half) * 256 + byte];
       }
     }
     stage_q(qid, 0);
 
     for (int t = 0; t < nqt; ++t) {
-      int qid_n = 0;
-      float thr_n = 0.f;
-      if (t + 1 < nqt) {
-        qid_n = a.lq_q[slot0 + 32 * (t + 1) + col];
-        thr_n = a.lq_thr[slot0 + 32 * (t + 1) + col];
-      }
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of tile t (and the operands at t = 0)
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nqt) stage_q(qid_n, (t + 1) & 1);
+      if (t + 1 < nqt) stage_q(qid1, (t + 1) & 1);
+      int qid2 = 0;      // tile t + 2's queries: in flight during this tile's products, waited for at the next meeting
+      float thr2 = 0.f;
+      if (t + 2 < nqt) {
+        qid2 = a.lq_q[slot0 + 32 * (t + 2) + col];
+        thr2 = a.lq_thr[slot0 + 32 * (t + 2) + col];
+      }
       __builtin_amdgcn_sched_barrier(0);
       const u32x4k* qb = qbuf + (size_t)(t & 1) * PU;
       f32x16 acc[RT];
@@ -904,6 +921,7 @@ __global__ __launch_bounds__(NW * 64) void k_lscan(LScanArgs a) {
       u32x4k bh[PF];
 #pragma unroll
       for (int s = 0; s < PF; ++s) bh[s] = qb[s * 64 + lane];
+      if (!(a.ablate & 2)) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const bf16x8 ch = __builtin_bit_cast(bf16x8, bh[s % PF]);
@@ -911,6 +929,10 @@ __global__ __launch_bounds__(NW * 64) void k_lscan(LScanArgs a) {
         for (int i = 0; i < RT; ++i)
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xh[i][s]), ch, acc[i], 0, 0, 0);
         if (s + PF < NS) bh[s % PF] = qb[(s + PF) * 64 + lane];
+      }
+      } else {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) acc[i][0] = __uint_as_float(xh[i][0][0] ^ xh[i][NS - 1][3] ^ bh[0][0]);
       }
       // filter (as k_l2_scan): tile maximum against the tile's smallest hx first, per row only where that passes
 #pragma unroll
@@ -921,7 +943,7 @@ __global__ __launch_bounds__(NW * 64) void k_lscan(LScanArgs a) {
         float m89 = fmaxf(fmaxf(c[12], c[13]), c[14]);
         const float mx = fmaxf(fmaxf(fmaxf(m01, m23), fmaxf(m45, m67)), fmaxf(m89, c[15]));
         if (mx >= hxmin[i] + thr && act[i]) {
-          const int r0 = off + seg * SEG + (wave * RT + i) * 32;
+          const int r0 = pos0 + (wave * RT + i) * 32;
           int h4 = 4 * half;
           asm volatile("" : "+v"(h4));
 #pragma unroll
@@ -941,8 +963,10 @@ __global__ __launch_bounds__(NW * 64) void k_lscan(LScanArgs a) {
           }
         }
       }
-      qid = qid_n;
-      thr = thr_n;
+      qid = qid1;
+      thr = thr1;
+      qid1 = qid2;
+      thr1 = thr2;
     }
   }
   __syncthreads();
@@ -1103,23 +1127,29 @@ __global__ __launch_bounds__(64) void k_probe_merge(const float* __restrict__ pd
   }
 }
 
-constexpr int kLNW = 8, kLRT = 2;  // workgroup = 8 waves x 2 tiles = 512 codes per work item
+constexpr int kLRT = 2;  // 32-code tiles per wave; a work item = NW x RT x 32 codes
+inline int lscan_nw() {  // waves per workgroup: 8 (one workgroup per CU) or 4 (two: one's operand gathers beside the other's products)
+  static const int nw = getenv("EIOKU_LSCAN_NW") ? atoi(getenv("EIOKU_LSCAN_NW")) : 8;
+  return nw == 4 ? 4 : 8;
+}
 
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct LWork {  // carve-up of the caller's workspace
   size_t qbf, qn, t1, tprobe, pd, pi, zero0, lcnt, cnt, overflow, nwork, zero1, cursor, loff, woff, lq_q, lq_p, lq_thr, wl, wl_cnt, cand,
-      total;
-  int nslots, grid, wl_cap, cap, K;
+      items, total;
+  int nslots, grid, wl_cap, cap, K, max_items;
 };
 
-LWork lwork(int nq, int d, int nprobe, int nlist, int k, int cap) {
+LWork lwork(int nq, int d, int nprobe, int nlist, int k, int cap, long long ntotal) {
   LWork w;
   const size_t npairs = (size_t)nq * nprobe;
   w.K = k <= 16 ? 16 : 32;
   w.cap = cap;
   w.nslots = (int)(npairs + 31 * (npairs < (size_t)nlist ? npairs : (size_t)nlist));
-  w.grid = num_cus();
+  w.grid = num_cus() * (8 / lscan_nw());
+  const int seg = lscan_nw() * kLRT * 32;
+  w.max_items = (int)(ntotal / seg + nlist);  // sum over lists of ceil(size / seg)
   long long wl_cap = ((32ll << 20) / 8) / w.grid;
   if (cap < 64) wl_cap = cap;  // tests shrink both kinds of list to force the overflow path
   w.wl_cap = (int)wl_cap;
@@ -1146,21 +1176,26 @@ LWork lwork(int nq, int d, int nprobe, int nlist, int k, int cap) {
   w.wl = take((size_t)w.grid * w.wl_cap * 8);
   w.wl_cnt = take((size_t)w.grid * 4);
   w.cand = take((size_t)nq * cap * 8);
+  w.items = take((size_t)w.max_items * 16);
   w.total = o;
   return w;
 }
 
-template <int NS>
-int launch_lscan(const LScanArgs& a, int grid, hipStream_t stream) {
-  const size_t lds = (size_t)2 * NS * 64 * 16 + (size_t)kLNW * kLRT * 32 * 4 + 16;
+template <int NS, int NW>
+int launch_lscan1(const LScanArgs& a, int grid, hipStream_t stream) {
+  const size_t lds = (size_t)2 * NS * 64 * 16 + (size_t)NW * kLRT * 32 * 4 + 16;
   static bool attr = false;
   if (!attr) {
-    EIOKU_HIP_CHECK(hipFuncSetAttribute((const void*)k_lscan<NS, kLNW, kLRT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    EIOKU_HIP_CHECK(hipFuncSetAttribute((const void*)k_lscan<NS, NW, kLRT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
-  hipLaunchKernelGGL((k_lscan<NS, kLNW, kLRT>), dim3((unsigned)grid), dim3(kLNW * 64), lds, stream, a);
+  hipLaunchKernelGGL((k_lscan<NS, NW, kLRT>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
   EIOKU_LAUNCH_CHECK();
   return EIOKU_OK;
+}
+template <int NS>
+int launch_lscan(const LScanArgs& a, int grid, hipStream_t stream) {
+  return lscan_nw() == 4 ? launch_lscan1<NS, 4>(a, grid, stream) : launch_lscan1<NS, 8>(a, grid, stream);
 }
 
 bool lists_geometry_ok(int d, int m) { return m * 8 == d && (d == 64 || d == 128 || d == 256 || d == 384); }
@@ -1189,9 +1224,9 @@ int eioku_ivfpq_lists_aux(const uint8_t* list_codes_dev, const int* offsets_dev,
 }
 
 // bytes of workspace eioku_ivfpq_search_lists needs (cand_cap: per-query candidate capacity, 0 = default 4096)
-long long eioku_ivfpq_lists_workspace(int nq, int d, int nprobe, int nlist, int k, int cand_cap) {
-  if (!initialised() || nq < 0 || nprobe <= 0 || nlist <= 0 || k < 1 || k > 32) return -1;
-  return (long long)lwork(nq, d, nprobe, nlist, k, cand_cap > 0 ? cand_cap : 4096).total;
+long long eioku_ivfpq_lists_workspace(int nq, int d, int nprobe, int nlist, long long ntotal, int k, int cand_cap) {
+  if (!initialised() || nq < 0 || nprobe <= 0 || nlist <= 0 || ntotal < 0 || k < 1 || k > 32) return -1;
+  return (long long)lwork(nq, d, nprobe, nlist, k, cand_cap > 0 ? cand_cap : 4096, ntotal).total;
 }
 
 // The whole search behind one call (all pointers DEVICE, asynchronous on `stream`): probes [nq][nprobe] from the coarse
@@ -1199,7 +1234,7 @@ long long eioku_ivfpq_lists_workspace(int nq, int d, int nprobe, int nlist, int 
 // D [nq][k], I [nq][k]: bit-identical to eioku_ivfpq_scan_tables + eioku_topk_merge_ex.  stats_out (optional, device,
 // 4 ints): overflow flag, work items, largest per-query candidate list, candidates of all queries.
 int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe, int nlist,
-                             const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
+                             long long ntotal, const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
                              const uint8_t* list_codes_dev, const long long* list_ids_dev, const float* list_tables_dev,
                              const float* query_tables_dev, const void* pqh_dev, const float* hx_dev,
                              const float* pmax2_dev, int k, int cand_cap, void* workspace_dev, long long workspace_bytes,
@@ -1213,7 +1248,8 @@ int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const lon
   EIOKU_REQUIRE((long long)nq * nprobe < (1ll << 30), "nq x nprobe too large for one call");
   if (nq == 0) return EIOKU_OK;
   const int cap = cand_cap > 0 ? cand_cap : 4096;
-  const LWork w = lwork(nq, d, nprobe, nlist, k, cap);
+  EIOKU_REQUIRE(ntotal >= 0 && ntotal < (1ll << 31), "ntotal out of range");
+  const LWork w = lwork(nq, d, nprobe, nlist, k, cap, ntotal);
   EIOKU_REQUIRE(workspace_bytes >= (long long)w.total, "workspace: %lld bytes given, %zu needed", workspace_bytes, w.total);
   const size_t rr_lds = (size_t)m * 256 * 4 + (size_t)cap * 12;
   EIOKU_REQUIRE(rr_lds <= 150 * 1024, "cand_cap %d needs %zu bytes of LDS", cap, rr_lds);
@@ -1248,12 +1284,20 @@ int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const lon
   long long* tprobe = (long long*)(ws + w.tprobe);
   hipLaunchKernelGGL(k_tau_probe, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, probes_dev, nq, nprobe, sizes_dev, k,
                      tprobe);
+  // ... of its first kTauRows rows: the k-th best of ANY k codes is a bound, and the whole list (9.9 k rows on average at
+  // 10 M rows) cost 0.30 ms per search for a bound that left 35 candidates per query; 1024 rows: see DESIGN.md
+  static const int tau_rows = getenv("EIOKU_LSCAN_TAU_ROWS") ? atoi(getenv("EIOKU_LSCAN_TAU_ROWS")) : 1024;
   int rc = scan_launch(q_dev, nq, d, m, tprobe, 1, coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev,
-                       list_ids_dev, k, pd, pi, list_tables_dev, query_tables_dev, stream_, 1, nullptr);
+                       list_ids_dev, k, pd, pi, list_tables_dev, query_tables_dev, stream_, 1, nullptr,
+                       tau_rows > k ? tau_rows : k);
   if (rc) return rc;
   hipLaunchKernelGGL(k_lq_fill, dim3((unsigned)std::min(1024, (w.nslots + 255) / 256)), dim3(256), 0, stream, lq_q, lq_thr, w.nslots);
   hipLaunchKernelGGL(k_inv_count, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, stream, probes_dev, npairs, sizes_dev, lcnt);
-  hipLaunchKernelGGL(k_inv_scan, dim3(1), dim3(1024), 0, stream, lcnt, sizes_dev, nlist, kLNW * kLRT * 32, loff, woff, cursor, nwork);
+  const int seg = lscan_nw() * kLRT * 32;
+  int4* items = (int4*)(ws + w.items);
+  hipLaunchKernelGGL(k_inv_scan, dim3(1), dim3(1024), 0, stream, lcnt, sizes_dev, nlist, seg, loff, woff, cursor, nwork);
+  hipLaunchKernelGGL(k_inv_items, dim3((unsigned)((w.max_items + 255) / 256)), dim3(256), 0, stream, woff, loff, offsets_dev,
+                     sizes_dev, nlist, seg, w.max_items, items);
   hipLaunchKernelGGL(k_inv_scatter, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, stream, probes_dev, npairs, nprobe,
                      sizes_dev, loff, cursor, t1, pd, w.K, k, qn, pmax2_dev, lq_q, lq_p, lq_thr);
   EIOKU_LAUNCH_CHECK();
@@ -1262,17 +1306,15 @@ int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const lon
   a.qbf = qbf;
   a.codes = list_codes_dev;
   a.hx = hx_dev;
-  a.offsets = offsets_dev;
-  a.sizes = sizes_dev;
-  a.loff = loff;
-  a.woff = woff;
+  a.items = items;
   a.nwork = nwork;
   a.lq_q = lq_q;
   a.lq_thr = lq_thr;
-  a.nlist = nlist;
   a.wl = wl;
   a.wl_cnt = wl_cnt;
   a.wl_cap = w.wl_cap;
+  static const int ablate = getenv("EIOKU_LSCAN_ABLATE") ? atoi(getenv("EIOKU_LSCAN_ABLATE")) : 0;
+  a.ablate = ablate;
   switch (d / 16) {
     case 4: rc = launch_lscan<4>(a, w.grid, stream); break;
     case 8: rc = launch_lscan<8>(a, w.grid, stream); break;

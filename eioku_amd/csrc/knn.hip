@@ -592,6 +592,65 @@ __global__ __launch_bounds__(64) void k_topk_merge(const float* pd, const int* p
 }
 
 
+// The same merge for L <= 64 SORTED lists of 32-bit ids (every search partial is one): a lane owns one list and only ever
+// looks at its head, so nothing is inserted - k rounds of wave argmin over the heads, the winner advances (its next
+// entry is already in a register, the one after it is in flight).  The general kernel above builds a K-deep sorted list
+// per lane first: 150 us for 1024 queries x 32 lists x 32 entries (the IVF probe selection), against ~10 us here.
+// Same order as above: (distance, id) ascending; ids are unique across lists.
+__global__ __launch_bounds__(64) void k_topk_merge_heads(const float* __restrict__ pd, const int* __restrict__ pi, int L, int kin,
+                                                         long long rows_per_list, int k, float* __restrict__ D,
+                                                         long long* __restrict__ I, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
+  const int q = blockIdx.x, lane = threadIdx.x;
+  // partial layout [qtile][list][kQT][kin]
+  const bool have = lane < L;
+  const size_t base = ((((size_t)(q / kQT) * L + (have ? lane : 0)) * kQT) + (q % kQT)) * kin;
+  const long long idb = (long long)lane * rows_per_list;
+  int h = 0;  // entries consumed
+  float cv = FLT_MAX, nv = FLT_MAX;
+  int ci = -1, ni = -1;
+  if (have) {
+    cv = pd[base];
+    ci = pi[base];
+    if (kin > 1) {
+      nv = pd[base + 1];
+      ni = pi[base + 1];
+    }
+  }
+  for (int r = 0; r < k; ++r) {
+    float bv = ci < 0 ? FLT_MAX : cv;
+    long long bi = ci < 0 ? 0x7FFFFFFFFFFFFFFFll : (long long)ci + idb;
+    int bl = lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const long long oi = __shfl_xor(bi, off, 64);
+      const int ol = __shfl_xor(bl, off, 64);
+      if (ov < bv || (ov == bv && oi < bi) || (ov == bv && oi == bi && ol < bl)) {
+        bv = ov;
+        bi = oi;
+        bl = ol;
+      }
+    }
+    const bool found = bi != 0x7FFFFFFFFFFFFFFFll;
+    if (lane == 0) {
+      D[(size_t)q * k + r] = found ? bv : FLT_MAX;
+      I[(size_t)q * k + r] = found ? bi : -1;
+    }
+    if (found && lane == bl) {  // pop: the list is sorted and padded with id < 0 at its end
+      ++h;
+      cv = nv;
+      ci = ni;
+      if (h + 1 < kin && ni >= 0) {
+        nv = pd[base + h + 1];
+        ni = pi[base + h + 1];
+      } else {
+        ni = -1;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Scan path (large N, any nq): database tiles stationary in registers.
 //
@@ -1286,7 +1345,9 @@ int legacy_search(eioku_index* ix, const float* dq, int nq, int k, const float* 
   else rc = K == 16 ? launch_search_k<16, false>(d, a, grid, stream) : launch_search_k<32, false>(d, a, grid, stream);
   if (prof) prof_stop(EIOKU_PROF_KNN, stream);
   if (rc) return rc;
-  if (K == 1)
+  if (slabs <= 64 && K > 1)  // a lane per sorted partial list: heads only
+    hipLaunchKernelGGL(k_topk_merge_heads, dim3(nq), dim3(64), 0, stream, ix->pd, ix->pi, (int)slabs, K, stride, k, dD, dI, gate);
+  else if (K == 1)
     hipLaunchKernelGGL((k_topk_merge<1>), dim3(nq), dim3(64), 0, stream, ix->pd, ix->pi, (const long long*)nullptr,
                        (int)slabs, nq, K, 1, (const long long*)nullptr, stride, k, dD, dI, gate);
   else if (K == 16)

@@ -328,7 +328,7 @@ class IndexIVFPQ:
                                                        current_stream(q)), "eioku_ivfpq_lists_aux")
             self._aux = (pqh, hx, pmax2)
         pqh, hx, pmax2 = self._aux
-        need = int(self._lib.eioku_ivfpq_lists_workspace(nq, self.d, nprobe, self.nlist, k, self.cand_cap))
+        need = int(self._lib.eioku_ivfpq_lists_workspace(nq, self.d, nprobe, self.nlist, self.ntotal, k, self.cand_cap))
         if need < 0:
             raise _lib.EiokuHipError("eioku_ivfpq_lists_workspace: bad argument")
         if self._ws is None or self._ws.numel() < need:
@@ -336,7 +336,7 @@ class IndexIVFPQ:
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         stats = torch.zeros((4,), dtype=torch.int32, device=self.device)
-        _lib.check(self._lib.eioku_ivfpq_search_lists(ptr(q), nq, self.d, self.m, ptr(probes), nprobe, self.nlist, ptr(self.coarse),
+        _lib.check(self._lib.eioku_ivfpq_search_lists(ptr(q), nq, self.d, self.m, ptr(probes), nprobe, self.nlist, self.ntotal, ptr(self.coarse),
                                                       ptr(self.pq), ptr(offsets), ptr(sizes), ptr(list_codes), ptr(list_ids),
                                                       ptr(self._list_tables), ptr(qt), ptr(pqh), ptr(hx), ptr(pmax2), k,
                                                       self.cand_cap, ptr(self._ws), self._ws.numel(), ptr(D), ptr(I), ptr(stats),

@@ -333,9 +333,9 @@ int eioku_ivfpq_scan_tables(const float* q_dev, int nq, int d, int m, const long
 int eioku_ivfpq_lists_aux(const uint8_t* list_codes_dev, const int* offsets_dev, const int* sizes_dev, int nlist, int d, int m,
                           const float* list_tables_dev, const float* pq_dev, void* pqh_out_dev, float* hx_out_dev,
                           float* pmax2_out_dev, void* stream);
-long long eioku_ivfpq_lists_workspace(int nq, int d, int nprobe, int nlist, int k, int cand_cap);
+long long eioku_ivfpq_lists_workspace(int nq, int d, int nprobe, int nlist, long long ntotal, int k, int cand_cap);
 int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe, int nlist,
-                             const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
+                             long long ntotal, const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
                              const uint8_t* list_codes_dev, const long long* list_ids_dev, const float* list_tables_dev,
                              const float* query_tables_dev, const void* pqh_dev, const float* hx_dev,
                              const float* pmax2_dev, int k, int cand_cap, void* workspace_dev, long long workspace_bytes,

@@ -48,7 +48,8 @@ def main():
     iters = 5
     times = {}
     ix.scan_mode = "queries"
-    for pre in (False, True):  # look-up tables from the codebook per (query, list) / FAISS' precomputed-table form (default)
+    lists_only = os.environ.get("IVFPQ_LISTS_ONLY") == "1"  # profiling runs: only the default path in the kernel statistics
+    for pre in (() if lists_only else (False, True)):  # look-up tables from the codebook per (query, list) / FAISS' precomputed-table form (default)
         ix.use_precomputed_table = pre
         for _ in range(2):
             D, I = ix.search(q, k)
@@ -58,7 +59,12 @@ def main():
             D, I = ix.search(q, k)
         torch.cuda.synchronize()
         times[pre] = (time.perf_counter() - t0) / iters
-    Dq, Iq = D, I
+    if lists_only:
+        times = {True: float("nan"), False: float("nan")}
+        ix.use_precomputed_table = True
+        iters = 20
+    else:
+        Dq, Iq = D, I
     ix.scan_mode = "lists"  # round 3: list-major scan (the default)
     for _ in range(2):
         D, I = ix.search(q, k)
@@ -68,7 +74,7 @@ def main():
         D, I = ix.search(q, k)
     torch.cuda.synchronize()
     t_search = (time.perf_counter() - t0) / iters
-    identical = bool(torch.equal(D, Dq) and torch.equal(I, Iq))
+    identical = None if lists_only else bool(torch.equal(D, Dq) and torch.equal(I, Iq))
     stats = ix.last_stats.cpu().tolist()
 
     flat = search.IndexFlatL2(d)
@@ -87,7 +93,8 @@ def main():
     print(json.dumps({"metric": "IVF-PQ build + search", "n": n, "d": d, "nlist": nlist, "m": m, "nprobe": nprobe, "nq": nq, "k": k,
                       "train_s": t_train, "add_s": t_add, "add_vectors_per_s": n / t_add, "search_ms": t_search * 1e3,
                       "qps": nq / t_search, "search_ms_query_major": times[True] * 1e3, "search_ms_query_major_tables_from_codebook": times[False] * 1e3,
-                      "list_major_identical_to_query_major": identical, "overflow_flag": stats[0], "work_items": stats[1],
+                      "list_major_identical_to_query_major": identical, "overflow_flag": stats[0], "work_items": stats[1], "largest_candidate_list": stats[2],
+                      "candidates_per_query": stats[3] / nq,
                       "code_bytes_list_major": float(n) * m, "recall_at_10_vs_flat": hit, "planted_neighbour_in_top10": planted,
                       "planted_neighbour_is_flat_top1": planted_flat,
                       "code_bytes_per_search": codes_scanned, "code_GBps": codes_scanned / t_search / 1e9,
