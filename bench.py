@@ -15,7 +15,10 @@ stream inside the timed region; `cpu_baseline` is the CPU oracle on a bounded sa
 The kNN part runs after the timed frames region: rows sharded over ranks, replicated queries, one
 RCCL all-gather + local merge per search.  `frames_1080p` repeats the frames measurement on the north star's
 own source size (64 x 1080 x 1920 BGR frames per step: bilinear letterbox to 384 x 640) with its own roofline.
-See DESIGN.md "Measurement".
+`cfg3` / `cfg4` / `cfg5` carry BASELINE.json's remaining configurations in the same driver-run line (MiniLM 512 x 128 +
+flat kNN over 1 M x 384; YOLOv8m objects + yolov8n-face on 64 x 1080p; IVF-PQ over a 12.5 M x 384 shard per GPU).
+`python bench.py --gpus N` without WORLD_SIZE starts its own N ranks (a child `python -m torch.distributed.run`, spawned
+before anything touches the GPU) and relays their line.  See DESIGN.md "Measurement".
 """
 from __future__ import annotations
 
@@ -36,7 +39,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -60,7 +63,38 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU oracle sample budget")
     ap.add_argument("--no-1080p", action="store_true", help="skip the frames_1080p block")
     ap.add_argument("--knn-mode", type=int, default=-1, help="scan_mode of the index: 0 register-tile kernels, 1 scan path (-1: library default)")
-    return ap.parse_args()
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg3 block (MiniLM 512 x 128, flat kNN 1 M x 384)")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the cfg4 block (YOLOv8m + yolov8n-face on 64 x 1080p)")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg5 block (IVF-PQ over a 12.5 M x 384 shard per GPU)")
+    ap.add_argument("--ivfpq-n", type=int, default=12_500_000, help="rows per GPU of the cfg5 index (100 M / 8)")
+    ap.add_argument("--cfg-steps", type=int, default=12, help="timed steps of the cfg4 frame runs")
+    return ap.parse_args(argv)
+
+
+def launcher_decision(gpus: int, env) -> str:
+    """How this invocation runs: "ranked" = one rank of a torch.distributed.run job (RANK / WORLD_SIZE in the environment:
+    the driver's N > 1 launch), "spawn" = `python bench.py --gpus N>1` on its own: start the N ranks as a child job,
+    "inline" = a single GPU in this process."""
+    if "WORLD_SIZE" in env or "RANK" in env:
+        return "ranked"
+    return "spawn" if gpus > 1 else "inline"
+
+
+def spawn_ranks(gpus: int, argv) -> int:
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <argv>` as a CHILD process (never an
+    exec: this must also be safe from a process that has touched the GPU, and this one has not); its stdout - rank 0's
+    JSON line - passes straight through.  Returns the child's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def kernel_source_hash() -> str:
@@ -265,6 +299,151 @@ def knn_part(args, device, rank, world):
     return out
 
 
+def cfg3_block(args, device, rank, world):
+    """BASELINE cfg3 on this GPU: all-MiniLM-L6-v2 on 512 segments x 128 tokens (bf16-MFMA roofline on SURVEY 8d's
+    22.4 MFLOP / token) and flat kNN over 1 M x 384 at nq 1 / 64 / 1024."""
+    import torch
+
+    from eioku_amd import _lib, embed, search, synth
+
+    out = {"config": "all-MiniLM-L6-v2 (random-init, fp32 in/out, split-bf16 MFMA) embed batch 512 x seq 128; IndexFlatL2 kNN over 1M x 384, top-10"}
+    enc = embed.MiniLMEncoder(embed.random_state(embed.MINILM_L6_V2, 11))
+    g = torch.Generator(device="cpu").manual_seed(11 + rank)
+    ids = torch.randint(1000, 30000, (512, 128), generator=g, dtype=torch.int32).to(device)
+    mask = torch.ones((512, 128), dtype=torch.uint8, device=device)
+    for _ in range(2):
+        enc.encode_ids(ids, mask)
+    torch.cuda.synchronize()
+    iters = 5
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        enc.encode_ids(ids, mask)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    _lib.prof_enable(True, tags=[_lib.PROF_GEMM])
+    _lib.prof_reset()
+    enc.encode_ids(ids, mask)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    gemm_ms, gemm_cnt = _lib.prof_read(_lib.PROF_GEMM)
+    alg = 512 * 128 * 22.4e6  # SURVEY 8d
+    out["minilm"] = {"metric": "segments/s (512 x 128 tokens)", "value": 512 / dt, "ms_per_batch": dt * 1e3, "dtype": "f32 (3-term split-bf16 products, fp32 accumulate)",
+                     "roofline": {"kernel": "K8 encoder forward (k_gemm_bf_s GEMMs + attention + add/LN + pooling; whole batch)",
+                                  "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F16_PEAK_TFLOPS, "achieved": alg / dt / 1e12,
+                                  "frac": alg / dt / 1e12 / MFMA_F16_PEAK_TFLOPS, "algorithmic_flops_per_batch": alg,
+                                  "executed_flops_per_batch": enc.last_flops(), "gemm_kernel_ms_per_batch": gemm_ms,
+                                  "gemm_launches": gemm_cnt,
+                                  "note": "achieved = 22.4 MFLOP/token x 65536 tokens over the wall time of one encode; the matrix pipe "
+                                          "executes 3 bf16 terms per product (x3 on the pipe)"}}
+    enc.close()
+    n = 1_000_000
+    xb = synth.normal_f32(21 + rank, n, 384, device, l2_normalise=True)
+    ix = search.IndexFlatL2(384)
+    ix.attach(xb)
+    knn = {}
+    for nq in (1, 64, 1024):
+        q = synth.normal_f32(22, nq, 384, device, l2_normalise=True)
+        for _ in range(2):
+            ix.search(q, 10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ix.search(q, 10)
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t0) / 5
+        knn[f"nq{nq}"] = {"ms_per_search": per * 1e3, "qps": nq / per, "algorithmic_GBps_one_pass": n * 384 * 4 / per / 1e9,
+                          "algorithmic_TFLOPs": 2.0 * nq * n * 384 / per / 1e12}
+    out["knn_1Mx384_top10"] = knn
+    ix.close()
+    del xb
+    return out
+
+
+def cfg5_block(args, device, rank, world):
+    """BASELINE cfg5 on this GPU's share: IndexIVF-PQ build + search over ivfpq_n x 384 rows per GPU (100 M / 8 = 12.5 M),
+    nlist 4096, m 48 (8-bit), nprobe 32 (SURVEY 8d fixes m and nprobe).  Rows are generated on the device (20 000
+    clusters + noise; queries = rows + a small perturbation, each with a planted neighbour).  world > 1: the quantisers
+    are trained on the union of the shards (one integer all-reduce per k-means iteration), every rank adds and scans its
+    own rows, one all-gather merges the top-k."""
+    import torch
+    import torch.distributed as dist
+
+    from eioku_amd import _lib, ivfpq, search, synth
+
+    n, d, nlist, m, nprobe, nq, k = args.ivfpq_n, 384, 4096, 48, 32, 1024, 10
+    ncl, sigma = 20000, 0.02
+    centres = synth.normal_f32(5, ncl, d, device, l2_normalise=True)
+    assign = torch.randint(0, ncl, (n,), device=device, generator=torch.Generator(device=device).manual_seed(6 + rank))
+    xb = torch.empty((n, d), dtype=torch.float32, device=device)
+    step = 2_500_000
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        xb[lo:hi] = centres[assign[lo:hi]] + sigma * synth.normal_f32(100 + 16 * rank + lo // step, hi - lo, d, device)
+    qa = torch.randint(0, n, (nq,), device=device, generator=torch.Generator(device=device).manual_seed(7))
+    q = xb[qa] + 0.1 * sigma * synth.normal_f32(9, nq, d, device)
+    if world > 1:  # the same queries on every rank: rank 0's
+        dist.broadcast(q, src=0)
+    torch.cuda.synchronize()
+    ix = ivfpq.IndexIVFPQ(d, nlist, m, device=device)
+    t0 = time.perf_counter()
+    ix.train(xb, group=dist.group.WORLD if world > 1 else None)
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for lo in range(0, n, step):
+        ix.add(xb[lo:min(n, lo + step)])
+    offsets, sizes, _, _ = ix._pack()
+    torch.cuda.synchronize()
+    t_add = time.perf_counter() - t0
+    ix.nprobe = nprobe
+    sh = search.ShardedFlatL2(ix, id_base=rank * n)
+    for _ in range(2):
+        D, I = sh.search(q, k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    iters = 5
+    _lib.prof_enable(True, tags=[_lib.PROF_IVFPQ])
+    _lib.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        D, I = sh.search(q, k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / iters
+    _lib.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([per], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per = float(t.item())
+    scan_ms, cnt = _lib.prof_read(_lib.PROF_IVFPQ)
+    scan_s = max(scan_ms * 1e-3 / max(cnt, 1), 1e-9)
+    stats = ix.last_stats.cpu().tolist()
+    _, probes = ix._quantizer.search_many(q, nprobe)
+    probed = float(sizes.long()[probes.clamp(min=0)].sum().item()) * m  # bytes a query-major scan of THIS index reads
+    alg = float(nq) * nprobe * (float(n) / nlist) * m                    # SURVEY 8d: nprobe (N / nlist) m bytes per query
+    planted = (I[:, 0] == qa + 0).float().mean().item() if world == 1 else None
+    out = {"metric": f"IVF-PQ QPS@top-10, {n} x {d} rows per GPU (nlist {nlist}, m {m}, nprobe {nprobe})", "value": nq * 1.0 / per,
+           "unit": "queries/s", "nq": nq, "k": k, "ms_per_search": per * 1e3, "rows_per_gpu": n, "n_total": n * world,
+           "train_s": t_train, "add_s": t_add, "add_vectors_per_s": n / t_add, "dtype": "u8 codes; f32 ADC distances (bf16 MFMA filter + exact fp32 re-rank)",
+           "planted_neighbour_first": planted, "overflow_flag": stats[0], "work_items": stats[1], "candidates_per_query": stats[3] / nq,
+           "largest_candidate_list": stats[2],
+           "collective": "none" if world == 1 else "int64 all-reduce per k-means iteration (build); all_gather of nq*k*16 B per rank (search)",
+           "roofline": {"kernel": "k_lscan (list-major ADC scan: a list segment's codes decoded once into bf16 MFMA operands, every probing "
+                                  "query streamed past them)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "achieved": alg / scan_s / 1e9, "frac": alg / scan_s / 1e9 / HBM_PEAK_GBS, "avg_kernel_ms": scan_s * 1e3,
+                        "algorithmic_bytes_per_launch": alg, "code_bytes_streamed_per_launch": float(stats[1]) * 512 * m,
+                        "code_bytes_of_the_probed_lists_query_major": probed, "code_bytes_in_index": float(n) * m,
+                        "note": "achieved = SURVEY 8d's per-query figure (nprobe x N/nlist x m bytes) x nq over the scan kernel's HIP-event "
+                                "duration; the list-major scan reads each probed list's codes once per SEARCH (code_bytes_streamed), so "
+                                "the algorithmic figure can exceed what crosses HBM; coarse quantiser, bound pass, inversion, "
+                                "re-rank are inside ms_per_search, not in it"}}
+    ix._quantizer.close()
+    del xb
+    return out
+
+
 def cpu_baseline(args, stages):
     """CPU oracle (numpy / torch-CPU port) on a bounded sample of the same workload: frames/s."""
     import numpy as np
@@ -273,12 +452,13 @@ def cpu_baseline(args, stages):
     from eioku_amd import embed, weights as W
     from oracle import bert as obert, prng, scene as oscene, yolo as oy
 
-    n = 2
+    n = 8  # frames per pass: a batch torch-CPU can spread over its threads
     frames = prng.synth_frames_bgr(1234, n, args.height, args.width)
     net = None
     if "detect" in stages:
         variant, nc, _ = W.variant_from_model_name(args.model)
-        net = oy.Net(W.random_state(variant, nc, 7), *W.YOLO_VARIANTS[variant], nc)
+        # fp32, as the reference predicts on the CPU (model_manager.py:270-275: Ultralytics half=False)
+        net = oy.Net(W.random_state(variant, nc, 7), *W.YOLO_VARIANTS[variant], nc, fp16=False)
     bert_state = embed.random_state(embed.MINILM_L6_V2, 11) if "embed" in stages else None
     seg_per_frame = args.segments / args.batch
     rng = np.random.default_rng(0)
@@ -302,13 +482,17 @@ def cpu_baseline(args, stages):
             break
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle stages {'+'.join(stages)} on {n} synthetic {args.height}x{args.width} frames per pass "
+            "sample": f"oracle stages {'+'.join(stages)} (fp32 network, the reference's CPU precision) on {n} synthetic {args.height}x{args.width} frames per pass "
                       f"({seg_per_frame:.3f} segments/frame), {done} frames in {dt:.1f}s; numpy + torch-CPU "
                       f"({torch.get_num_threads()} threads)"}
 
 
 def main():
     args = parse_args()
+    if launcher_decision(args.gpus, os.environ) == "spawn":  # before torch / the library / any HIP call
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    import copy
+
     import torch
     import torch.distributed as dist
 
@@ -317,10 +501,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world  # the job's size is what the launcher made it
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     _lib.init(local_rank)
@@ -341,7 +522,7 @@ def main():
             return i == args.steps // 2
         return args.prof_every > 0 and i % args.prof_every == 0
 
-    def run_frames(height, width):
+    def run_frames(height, width, args=args):
         """warm-up, then EXACTLY args.steps timed steps between barrier + synchronize pairs; max over ranks."""
         pipe = Pipeline(args, device, rank, height, width)
         for i in range(args.warmup):
@@ -428,6 +609,30 @@ def main():
         out["frames_1080p"] = {"metric": out["metric"], "unit": "frames/s", "steps": args.steps, "warmup": args.warmup, **blk}
     if args.knn_n > 0:
         out["knn"] = knn_part(args, device, rank, world)
+
+    def guarded(name, fn):
+        """a side block must not take the headline down with it (its error is part of the line instead)"""
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+
+    if not args.no_cfg3:
+        guarded("cfg3", lambda: cfg3_block(args, device, rank, world))
+    if not args.no_cfg4:
+        def cfg4():
+            blk = {"config": "BASELINE cfg4's models on 64 x 1080p sources per step per GPU (scene + detect + embed each); "
+                             "random-init weights, head calibrated to ~1 % of anchors above conf"}
+            for key, model in (("objects_yolov8m", "yolov8m.pt"), ("faces_yolov8n_face", "yolov8n-face.pt")):
+                a4 = copy.copy(args)
+                a4.model, a4.steps, a4.prof_every = model, args.cfg_steps, -1
+                r, _ = run_frames(1080, 1920, a4)
+                blk[key] = {"metric": out["metric"], "unit": "frames/s", "steps": a4.steps, "warmup": a4.warmup, **r}
+            return blk
+        guarded("cfg4", cfg4)
+    if not args.no_cfg5:
+        guarded("cfg5", lambda: cfg5_block(args, device, rank, world))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, stages)
     if world > 1:

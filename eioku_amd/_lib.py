@@ -191,7 +191,7 @@ def device_info() -> dict:
     return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
 
 
-PROF_SCENE_SAD, PROF_SCENE_HSV, PROF_CONV, PROF_KNN, PROF_GEMM = 0, 1, 2, 3, 4
+PROF_SCENE_SAD, PROF_SCENE_HSV, PROF_CONV, PROF_KNN, PROF_GEMM, PROF_IVFPQ = 0, 1, 2, 3, 4, 5
 
 
 def prof_enable(on: bool, tags=None) -> None:

@@ -200,7 +200,7 @@ __device__ __forceinline__ float term1_block(const float* __restrict__ qrow, con
 
 // grid (nq, probes scanned <= nprobe); block 256.  probes: [nq][nprobe] list ids (-1 = none).
 // out: pd/pi [nprobe][nq][K]  (the [list][nq][k] layout k_topk_merge takes)
-// gate (optional): device word, the launch is a no-op when *gate == 0 (fallback of the list-major path)
+// gate (optional): device word + per-query candidate counts, see the first statement (fallback of the list-major path)
 template <int K, int DSUB, bool PRE = false>
 __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q, int nq, int d, int m,
                                                     const long long* __restrict__ probes, int nprobe,
@@ -210,9 +210,12 @@ __global__ __launch_bounds__(256) void k_ivfpq_scan(const float* __restrict__ q,
                                                     const long long* __restrict__ list_ids, float* __restrict__ pd,
                                                     long long* __restrict__ pi, const float* __restrict__ t2 = nullptr,
                                                     const float* __restrict__ t3 = nullptr,
-                                                    const int* __restrict__ gate = nullptr, int max_rows = 0) {
+                                                    const int* __restrict__ gate = nullptr, int max_rows = 0,
+                                                    const int* __restrict__ qcnt = nullptr, int qcap = 0) {
   extern __shared__ __attribute__((aligned(16))) float lut[];  // [m][256], then merge area
-  if (gate && *gate == 0) return;  // uniform
+  // fallback of the list-major path: runs for every query when bit 0 of *gate is set (a workgroup list overflowed), else
+  // only for the queries whose own candidate list overflowed
+  if (gate && !(*gate & 1) && !(qcnt && qcnt[blockIdx.x] > qcap)) return;  // uniform
   const int qi = blockIdx.x, pr = blockIdx.y, tid = threadIdx.x;
   const long long l = probes[(size_t)qi * nprobe + pr];
   SmallTop<K> top;
@@ -497,7 +500,7 @@ int scan_launch(const float* q_dev, int nq, int d, int m, const long long* probe
                 const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
                 const uint8_t* list_codes_dev, const long long* list_ids_dev, int k, float* pd_dev,
                 long long* pi_dev, const float* t2_dev, const float* t3_dev, void* stream_, int nscan = 0,
-                const int* gate = nullptr, int max_rows = 0) {
+                const int* gate = nullptr, int max_rows = 0, const int* qcnt = nullptr, int qcap = 0) {
   EIOKU_REQUIRE_INIT();
   EIOKU_REQUIRE(q_dev && probes_dev && coarse_dev && pq_dev && offsets_dev && sizes_dev && pd_dev && pi_dev, "NULL buffer");
   EIOKU_REQUIRE(nq >= 0 && nprobe > 0 && k >= 1 && k <= 32 && d % m == 0, "bad argument");
@@ -523,7 +526,7 @@ int scan_launch(const float* q_dev, int nq, int d, int m, const long long* probe
     }                                                                                                          \
     hipLaunchKernelGGL((k_ivfpq_scan<K_, D_, P_>), grid, dim3(256), lds, stream, q_dev, nq, d, m, probes_dev, nprobe, \
                        coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev, list_ids_dev, pd_dev, pi_dev, \
-                       t2_dev, t3_dev, gate, max_rows);                                                        \
+                       t2_dev, t3_dev, gate, max_rows, qcnt, qcap);                                            \
   }
 #define EIOKU_SCAN(K_, D_) \
   if (pre) EIOKU_SCAN1(K_, D_, true) else EIOKU_SCAN1(K_, D_, false)
@@ -995,7 +998,10 @@ __global__ __launch_bounds__(256) void k_lbin(const unsigned* __restrict__ wl, c
 }
 
 // one workgroup per query: the candidates' ADC distances with the query-major kernel's arithmetic
-// (sum_j (T2[l][j][c] + T3[q][j][c]) in j order, + t1), then the k best by (distance, id)
+// (sum_j (T2[l][j][c] + T3[q][j][c]) in j order, + t1), then the k best by (distance, id).  Candidates are scored in
+// chunks of kRChunk; the best k so far ride along as extra entries of the next chunk, so the list a query may hold is
+// bounded by the global buffer (cap), not by LDS.
+constexpr int kRChunk = 2048;
 __global__ __launch_bounds__(256) void k_lrerank(const int* __restrict__ cand, const int* __restrict__ cnt, int cap, int m,
                                                  const int* __restrict__ lq_p, const long long* __restrict__ probes,
                                                  const float* __restrict__ t1, const float* __restrict__ t2,
@@ -1005,91 +1011,123 @@ __global__ __launch_bounds__(256) void k_lrerank(const int* __restrict__ cand, c
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   const int nent = m * 256;
   float* s_t3 = reinterpret_cast<float*>(dyn_smem);            // [m * 256]
-  long long* s_id = reinterpret_cast<long long*>(s_t3 + nent);  // [cap]
-  float* s_d = reinterpret_cast<float*>(s_id + cap);            // [cap]
-  __shared__ float s_bv[4];
-  __shared__ long long s_bi[4];
+  long long* s_id = reinterpret_cast<long long*>(s_t3 + nent);  // [kRChunk + 32]
+  float* s_d = reinterpret_cast<float*>(s_id + kRChunk + 32);   // [kRChunk + 32]
+  __shared__ float s_bv[4], s_kv[32];
+  __shared__ long long s_bi[4], s_ki[32];
   const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int c = cnt[qi];
   if (tid == 0) {
     atomicMax(overflow + 2, c);
     atomicAdd(overflow + 3, c);
+    atomicMax(reinterpret_cast<unsigned long long*>(overflow + 4), ((unsigned long long)c << 32) | (unsigned)qi);
   }
-  if (c > cap) {
-    if (tid == 0) atomicOr(overflow, 1);
+  if (c > cap) {  // this query is redone by the gated query-major launches that follow
+    if (tid == 0) atomicOr(overflow, 2);
     c = cap;
   }
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   for (int e4 = tid; e4 < nent / 4; e4 += 256)
     reinterpret_cast<f32x4*>(s_t3)[e4] = reinterpret_cast<const f32x4*>(t3 + (size_t)qi * nent)[e4];
+  int kept = 0;  // entries of s_kv / s_ki: the best of the chunks so far
   __syncthreads();
-  for (int j = tid; j < c; j += 256) {
-    const int slot = cand[((size_t)qi * cap + j) * 2], pos = cand[((size_t)qi * cap + j) * 2 + 1];
-    const int p = lq_p[slot];
-    const long long l = probes[p];
-    const float* tl = t2 + (size_t)l * nent;
-    const uint8_t* code = codes + (size_t)pos * m;
-    float s = 0.f;
-    for (int jj = 0; jj < m; ++jj) {
-      const int e = jj * 256 + code[jj];
-      s += tl[e] + s_t3[e];
-    }
-    s_d[j] = s + t1[p];
-    s_id[j] = ids[pos];
-  }
-  __syncthreads();
-  float lv = -__builtin_inff();
-  long long li = -1;
-  for (int r = 0; r < k; ++r) {
-    float bv = FLT_MAX;
-    long long bi = 0x7FFFFFFFFFFFFFFFll;
-    for (int j = tid; j < c; j += 256) {
-      const float v = s_d[j];
-      const long long i = s_id[j];
-      const bool after = v > lv || (v == lv && i > li);
-      if (after && (v < bv || (v == bv && i < bi))) {
-        bv = v;
-        bi = i;
-      }
-    }
+  for (int c0 = 0; c0 == 0 || c0 < c; c0 += kRChunk) {
+    const int cc = min(kRChunk, c - c0);
+    for (int j = tid; j < cc; j += 256) {
+      const int slot = cand[((size_t)qi * cap + c0 + j) * 2], pos = cand[((size_t)qi * cap + c0 + j) * 2 + 1];
+      const int p = lq_p[slot];
+      const long long l = probes[p];
+      const float* tl = t2 + (size_t)l * nent;
+      const uint8_t* code = codes + (size_t)pos * m;
+      // 8 table entries in flight per thread (one load -> add -> next load chain per entry was 48 dependent L2 round
+      // trips per candidate: a query holding thousands of candidates took longer than the whole scan); the sum itself
+      // stays sequential in j, as in the query-major kernel
+      float s = 0.f;
+      for (int j0 = 0; j0 < m; j0 += 8) {  // m is a multiple of 8 (d / m = 8, d a multiple of 64)
+        const u32x2k cw = *reinterpret_cast<const u32x2k*>(code + j0);
+        float a[8], b[8];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const long long oi = __shfl_xor(bi, o, 64);
-      if (ov < bv || (ov == bv && oi < bi)) {
-        bv = ov;
-        bi = oi;
+        for (int u = 0; u < 8; ++u) {
+          const int e = (j0 + u) * 256 + (int)((cw[u >> 2] >> (8 * (u & 3))) & 0xFFu);
+          a[u] = tl[e];
+          b[u] = s_t3[e];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += a[u] + b[u];
       }
+      s_d[j] = s + t1[p];
+      s_id[j] = ids[pos];
     }
-    if (lane == 0) {
-      s_bv[wave] = bv;
-      s_bi[wave] = bi;
+    if (tid < kept) {
+      s_d[cc + tid] = s_kv[tid];
+      s_id[cc + tid] = s_ki[tid];
     }
     __syncthreads();
-    bv = s_bv[0];
-    bi = s_bi[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w)
-      if (s_bv[w] < bv || (s_bv[w] == bv && s_bi[w] < bi)) {
-        bv = s_bv[w];
-        bi = s_bi[w];
+    const int tot = cc + kept;
+    const bool last = c0 + kRChunk >= c;
+    float lv = -__builtin_inff();
+    long long li = -1;
+    int found = 0;
+    for (int r = 0; r < k; ++r) {
+      float bv = FLT_MAX;
+      long long bi = 0x7FFFFFFFFFFFFFFFll;
+      for (int j = tid; j < tot; j += 256) {
+        const float v = s_d[j];
+        const long long i = s_id[j];
+        const bool after = v > lv || (v == lv && i > li);
+        if (after && (v < bv || (v == bv && i < bi))) {
+          bv = v;
+          bi = i;
+        }
       }
-    __syncthreads();
-    const bool none = bi == 0x7FFFFFFFFFFFFFFFll;
-    if (tid == 0) {
-      Dout[(size_t)qi * k + r] = none ? FLT_MAX : bv;
-      Iout[(size_t)qi * k + r] = none ? -1 : bi;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const long long oi = __shfl_xor(bi, o, 64);
+        if (ov < bv || (ov == bv && oi < bi)) {
+          bv = ov;
+          bi = oi;
+        }
+      }
+      if (lane == 0) {
+        s_bv[wave] = bv;
+        s_bi[wave] = bi;
+      }
+      __syncthreads();
+      bv = s_bv[0];
+      bi = s_bi[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        if (s_bv[w] < bv || (s_bv[w] == bv && s_bi[w] < bi)) {
+          bv = s_bv[w];
+          bi = s_bi[w];
+        }
+      __syncthreads();
+      const bool none = bi == 0x7FFFFFFFFFFFFFFFll;
+      if (tid == 0) {
+        if (last) {
+          Dout[(size_t)qi * k + r] = none ? FLT_MAX : bv;
+          Iout[(size_t)qi * k + r] = none ? -1 : bi;
+        } else if (!none) {
+          s_kv[r] = bv;
+          s_ki[r] = bi;
+        }
+      }
+      if (!none) found = r + 1;
+      lv = none ? FLT_MAX : bv;
+      li = none ? 0x7FFFFFFFFFFFFFFFll : bi;
     }
-    lv = none ? FLT_MAX : bv;
-    li = none ? 0x7FFFFFFFFFFFFFFFll : bi;
+    kept = found;
+    __syncthreads();
   }
 }
 
 // fallback merge (gated): the query-major scan's [nprobe][nq][K] partial lists -> (D, I); one wave per query
 __global__ __launch_bounds__(64) void k_probe_merge(const float* __restrict__ pd, const long long* __restrict__ pi, int nprobe,
                                                     int nq, int K, int k, float* __restrict__ Dout,
-                                                    long long* __restrict__ Iout, const int* __restrict__ gate) {
-  if (gate && *gate == 0) return;
+                                                    long long* __restrict__ Iout, const int* __restrict__ gate,
+                                                    const int* __restrict__ qcnt, int qcap) {
+  if (gate && !(*gate & 1) && !(qcnt && qcnt[blockIdx.x] > qcap)) return;
   const int qi = blockIdx.x, lane = threadIdx.x;
   const int n = nprobe * K;
   float lv = -__builtin_inff();
@@ -1150,7 +1188,7 @@ LWork lwork(int nq, int d, int nprobe, int nlist, int k, int cap, long long ntot
   w.grid = num_cus() * (8 / lscan_nw());
   const int seg = lscan_nw() * kLRT * 32;
   w.max_items = (int)(ntotal / seg + nlist);  // sum over lists of ceil(size / seg)
-  long long wl_cap = ((32ll << 20) / 8) / w.grid;
+  long long wl_cap = ((64ll << 20) / 8) / w.grid;
   if (cap < 64) wl_cap = cap;  // tests shrink both kinds of list to force the overflow path
   w.wl_cap = (int)wl_cap;
   size_t o = 0;
@@ -1164,7 +1202,7 @@ LWork lwork(int nq, int d, int nprobe, int nlist, int k, int cap, long long ntot
   w.zero0 = o;
   w.lcnt = take((size_t)nlist * 4);
   w.cnt = take((size_t)nq * 4);
-  w.overflow = take(16);  // stats: overflow flag, work items, largest candidate list, candidates in all
+  w.overflow = take(32);  // stats: overflow bits, work items, largest candidate list, candidates in all, (count << 32 | query) max
   w.nwork = w.overflow + 4;
   w.zero1 = o;
   w.cursor = take((size_t)nlist * 4);
@@ -1223,16 +1261,18 @@ int eioku_ivfpq_lists_aux(const uint8_t* list_codes_dev, const int* offsets_dev,
   return EIOKU_OK;
 }
 
-// bytes of workspace eioku_ivfpq_search_lists needs (cand_cap: per-query candidate capacity, 0 = default 4096)
+// bytes of workspace eioku_ivfpq_search_lists needs (cand_cap: per-query candidate capacity, 0 = default 8192)
 long long eioku_ivfpq_lists_workspace(int nq, int d, int nprobe, int nlist, long long ntotal, int k, int cand_cap) {
   if (!initialised() || nq < 0 || nprobe <= 0 || nlist <= 0 || ntotal < 0 || k < 1 || k > 32) return -1;
-  return (long long)lwork(nq, d, nprobe, nlist, k, cand_cap > 0 ? cand_cap : 4096, ntotal).total;
+  return (long long)lwork(nq, d, nprobe, nlist, k, cand_cap > 0 ? cand_cap : 8192, ntotal).total;
 }
 
 // The whole search behind one call (all pointers DEVICE, asynchronous on `stream`): probes [nq][nprobe] from the coarse
 // quantiser, list_tables / query_tables as for eioku_ivfpq_scan_tables, pqh / hx / pmax2 from eioku_ivfpq_lists_aux.
 // D [nq][k], I [nq][k]: bit-identical to eioku_ivfpq_scan_tables + eioku_topk_merge_ex.  stats_out (optional, device,
-// 4 ints): overflow flag, work items, largest per-query candidate list, candidates of all queries.
+// 6 ints): overflow bits (1: a workgroup list overflowed, every query redone query-major; 2: some queries' own lists
+// overflowed, those redone), work items, largest per-query candidate list, candidates of all queries, the query that
+// holds the largest list, its size.
 int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const long long* probes_dev, int nprobe, int nlist,
                              long long ntotal, const float* coarse_dev, const float* pq_dev, const int* offsets_dev, const int* sizes_dev,
                              const uint8_t* list_codes_dev, const long long* list_ids_dev, const float* list_tables_dev,
@@ -1247,12 +1287,12 @@ int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const lon
   EIOKU_REQUIRE(lists_geometry_ok(d, m), "list-major scan: d/m must be 8 and d in {64, 128, 256, 384} (got d=%d m=%d)", d, m);
   EIOKU_REQUIRE((long long)nq * nprobe < (1ll << 30), "nq x nprobe too large for one call");
   if (nq == 0) return EIOKU_OK;
-  const int cap = cand_cap > 0 ? cand_cap : 4096;
+  const int cap = cand_cap > 0 ? cand_cap : 8192;
   EIOKU_REQUIRE(ntotal >= 0 && ntotal < (1ll << 31), "ntotal out of range");
   const LWork w = lwork(nq, d, nprobe, nlist, k, cap, ntotal);
   EIOKU_REQUIRE(workspace_bytes >= (long long)w.total, "workspace: %lld bytes given, %zu needed", workspace_bytes, w.total);
-  const size_t rr_lds = (size_t)m * 256 * 4 + (size_t)cap * 12;
-  EIOKU_REQUIRE(rr_lds <= 150 * 1024, "cand_cap %d needs %zu bytes of LDS", cap, rr_lds);
+  const size_t rr_lds = (size_t)m * 256 * 4 + (size_t)(kRChunk + 32) * 12;
+  EIOKU_REQUIRE(cap <= (1 << 20), "cand_cap %d too large", cap);
   hipStream_t stream = (hipStream_t)stream_;
   unsigned char* ws = (unsigned char*)workspace_dev;
   const int npairs = nq * nprobe;
@@ -1315,12 +1355,14 @@ int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const lon
   a.wl_cap = w.wl_cap;
   static const int ablate = getenv("EIOKU_LSCAN_ABLATE") ? atoi(getenv("EIOKU_LSCAN_ABLATE")) : 0;
   a.ablate = ablate;
+  prof_start(EIOKU_PROF_IVFPQ, stream);
   switch (d / 16) {
     case 4: rc = launch_lscan<4>(a, w.grid, stream); break;
     case 8: rc = launch_lscan<8>(a, w.grid, stream); break;
     case 16: rc = launch_lscan<16>(a, w.grid, stream); break;
     default: rc = launch_lscan<24>(a, w.grid, stream); break;
   }
+  prof_stop(EIOKU_PROF_IVFPQ, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(k_lbin, dim3((unsigned)w.grid), dim3(256), 0, stream, wl, wl_cnt, w.wl_cap, lq_q, cand, cnt, cap, overflow);
   {
@@ -1333,14 +1375,15 @@ int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const lon
   hipLaunchKernelGGL(k_lrerank, dim3((unsigned)nq), dim3(256), rr_lds, stream, cand, cnt, cap, m, lq_p, probes_dev, t1,
                      list_tables_dev, query_tables_dev, list_codes_dev, list_ids_dev, k, D_dev, I_dev, overflow);
   EIOKU_LAUNCH_CHECK();
-  // a candidate list overflowed (no contrast in the data, or a nearest list with fewer than k codes): the query-major
-  // scan redoes the search; both launches are no-ops otherwise
+  // a query's candidate list overflowed (no contrast around it, or no list with k codes to bound it): the query-major
+  // scan redoes THAT query; a workgroup list overflowed: it redoes all of them; both launches are no-ops otherwise
   rc = scan_launch(q_dev, nq, d, m, probes_dev, nprobe, coarse_dev, pq_dev, offsets_dev, sizes_dev, list_codes_dev,
-                   list_ids_dev, k, pd, pi, list_tables_dev, query_tables_dev, stream_, 0, overflow);
+                   list_ids_dev, k, pd, pi, list_tables_dev, query_tables_dev, stream_, 0, overflow, 0, cnt, cap);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)nq), dim3(64), 0, stream, pd, pi, nprobe, nq, w.K, k, D_dev, I_dev, overflow);
+  hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)nq), dim3(64), 0, stream, pd, pi, nprobe, nq, w.K, k, D_dev, I_dev, overflow,
+                     cnt, cap);
   EIOKU_LAUNCH_CHECK();
-  if (stats_out_dev) EIOKU_HIP_CHECK(hipMemcpyAsync(stats_out_dev, overflow, 16, hipMemcpyDeviceToDevice, stream));
+  if (stats_out_dev) EIOKU_HIP_CHECK(hipMemcpyAsync(stats_out_dev, overflow, 24, hipMemcpyDeviceToDevice, stream));
   return EIOKU_OK;
 }
 

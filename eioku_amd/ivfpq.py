@@ -142,10 +142,10 @@ class IndexIVFPQ:
         # "queries"); "queries": one workgroup per (query, probe).  "lists" needs d/m = 8, d in {64, 128, 256, 384} and the
         # precomputed tables; other geometries always take "queries".
         self.scan_mode = "lists"
-        self.cand_cap = 4096                # per-query candidate capacity of the list-major filter (overflow -> query-major redo)
+        self.cand_cap = 8192                # per-query candidate capacity of the list-major filter (overflow -> query-major redo)
         self._aux = None                    # (pqh, hx, pmax2) of the current pack
         self._ws = None
-        self.last_stats = None              # device int32[4] after a list-major search: overflow flag, work items, largest candidate list, candidates in all
+        self.last_stats = None              # device int32[6] after a list-major search: overflow bits, work items, largest candidate list, candidates in all, its query, its size
         self.allreduce_calls = 0
 
     # ---- training ------------------------------------------------------------------------------
@@ -335,7 +335,7 @@ class IndexIVFPQ:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
-        stats = torch.zeros((4,), dtype=torch.int32, device=self.device)
+        stats = torch.zeros((6,), dtype=torch.int32, device=self.device)
         _lib.check(self._lib.eioku_ivfpq_search_lists(ptr(q), nq, self.d, self.m, ptr(probes), nprobe, self.nlist, self.ntotal, ptr(self.coarse),
                                                       ptr(self.pq), ptr(offsets), ptr(sizes), ptr(list_codes), ptr(list_ids),
                                                       ptr(self._list_tables), ptr(qt), ptr(pqh), ptr(hx), ptr(pmax2), k,

@@ -66,6 +66,7 @@ enum {
   EIOKU_PROF_CONV = 2,
   EIOKU_PROF_KNN = 3,
   EIOKU_PROF_GEMM = 4,
+  EIOKU_PROF_IVFPQ = 5, /* k_lscan, the list-major ADC scan */
   EIOKU_PROF_NUM_TAGS = 8
 };
 int eioku_prof_enable(int on); /* 0 off, 1 all tags, else mask: bit (tag + 1) enables that tag only */
@@ -326,9 +327,10 @@ int eioku_ivfpq_scan_tables(const float* q_dev, int nq, int d, int m, const long
  *                                 hx_out [ntotal] floats, pmax2_out [nlist] floats.
  *   eioku_ivfpq_lists_workspace : bytes of device workspace one search of nq queries needs (-1: bad argument).
  *   eioku_ivfpq_search_lists    : the whole search; probes [nq][nprobe] from the coarse quantiser; cand_cap = per-query
- *                                 candidate capacity (0: 4096); a list that overflows gates the query-major scan in
- *                                 (same results, slower).  stats_out (optional, device, 4 ints): overflow flag, work items,
- *                                 largest per-query candidate list, candidates of all queries.
+ *                                 candidate capacity (0: 8192); a query whose list overflows is redone by the gated
+ *                                 query-major scan (same results, slower).  stats_out (optional, device, 6 ints): overflow
+ *                                 bits (1: every query redone, 2: some), work items, largest per-query candidate list,
+ *                                 candidates of all queries, the query holding the largest list, its size.
  * Replaces: FAISS IndexIVFPQ::search as planned by /root/reference/.kiro/specs/semantic-video-search/design.md:35-40,1105-1113. */
 int eioku_ivfpq_lists_aux(const uint8_t* list_codes_dev, const int* offsets_dev, const int* sizes_dev, int nlist, int d, int m,
                           const float* list_tables_dev, const float* pq_dev, void* pqh_out_dev, float* hx_out_dev,
