@@ -23,6 +23,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
@@ -41,6 +42,7 @@ Rccl* rccl() {
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.handle, "ncclCommAbort"));  // optional
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
@@ -68,6 +70,15 @@ Rccl* rccl() {
 
 // One rank's answer as a single message: [nq*k] float distances, padded to 8 bytes, then [nq*k] int64 global ids.
 __host__ __device__ inline size_t payload_words(long long n) { return (size_t)((n + 1) / 2 + n); }  // int64 words
+
+// a rank whose own search failed still owes its peers a message: all padding (FLT_MAX / -1), as an empty shard answers
+__global__ void k_pad_answer(long long n, long long* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  reinterpret_cast<float*>(out)[i] = 3.402823466e+38f;
+  if (i == n - 1 && (n & 1)) reinterpret_cast<float*>(out)[n] = 0.f;
+  out[(n + 1) / 2 + i] = -1;
+}
 
 __global__ void k_pack_answer(const float* __restrict__ D, const long long* __restrict__ I, long long n,
                               long long id_base, long long* __restrict__ out) {
@@ -158,49 +169,75 @@ int eioku_index_search_sharded(eioku_index_t* ix, eioku_comm_t* c, long long id_
   if (nq == 0) return EIOKU_OK;  // every rank passes the same nq: nobody enters the collective
   EIOKU_REQUIRE(q && D && I, "NULL buffer");
   EIOKU_RCCL_REQUIRE();
+  EIOKU_REQUIRE(c->comm, "the communicator was aborted by an earlier failure");
   hipStream_t stream = (hipStream_t)stream_;
   const long long n = (long long)nq * k;
   const size_t words = payload_words(n);
-  if (c->loc_cap < (size_t)n) {
-    (void)hipStreamSynchronize(stream);
-    if (c->Dloc) (void)hipFree(c->Dloc);
-    if (c->Iloc) (void)hipFree(c->Iloc);
-    c->Dloc = nullptr;
-    c->Iloc = nullptr;
-    c->loc_cap = 0;
-    EIOKU_HIP_CHECK(hipMalloc((void**)&c->Dloc, (size_t)n * sizeof(float)));
-    EIOKU_HIP_CHECK(hipMalloc((void**)&c->Iloc, (size_t)n * sizeof(long long)));
-    c->loc_cap = (size_t)n;
+  // Workspace first.  A rank that cannot even allocate its message cannot take part in the collective its peers are
+  // about to enter: it aborts the communicator (ncclCommAbort fails the peers' pending all-gather instead of leaving
+  // them blocked in it) and reports the error.  [The world > 1 path of this entry has not run on hardware yet: one-GPU
+  // leases only; tests/test_comm_gpu.py forms a world of one.]
+  auto grow_all = [&]() -> int {
+    if (c->loc_cap < (size_t)n) {
+      (void)hipStreamSynchronize(stream);
+      if (c->Dloc) (void)hipFree(c->Dloc);
+      if (c->Iloc) (void)hipFree(c->Iloc);
+      c->Dloc = nullptr;
+      c->Iloc = nullptr;
+      c->loc_cap = 0;
+      EIOKU_HIP_CHECK(hipMalloc((void**)&c->Dloc, (size_t)n * sizeof(float)));
+      EIOKU_HIP_CHECK(hipMalloc((void**)&c->Iloc, (size_t)n * sizeof(long long)));
+      c->loc_cap = (size_t)n;
+    }
+    if (c->msg_cap < words) {
+      (void)hipStreamSynchronize(stream);
+      if (c->send) (void)hipFree(c->send);
+      if (c->recv) (void)hipFree(c->recv);
+      c->send = c->recv = nullptr;
+      c->msg_cap = 0;
+      EIOKU_HIP_CHECK(hipMalloc((void**)&c->send, words * sizeof(long long)));
+      EIOKU_HIP_CHECK(hipMalloc((void**)&c->recv, words * sizeof(long long) * (size_t)c->world));
+      c->msg_cap = words;
+    }
+    if (c->list_cap < (size_t)n * c->world) {
+      (void)hipStreamSynchronize(stream);
+      if (c->dl) (void)hipFree(c->dl);
+      if (c->il) (void)hipFree(c->il);
+      c->dl = nullptr;
+      c->il = nullptr;
+      c->list_cap = 0;
+      EIOKU_HIP_CHECK(hipMalloc((void**)&c->dl, (size_t)n * c->world * sizeof(float)));
+      EIOKU_HIP_CHECK(hipMalloc((void**)&c->il, (size_t)n * c->world * sizeof(long long)));
+      c->list_cap = (size_t)n * c->world;
+    }
+    return EIOKU_OK;
+  };
+  int rc = grow_all();
+  if (rc != EIOKU_OK) {
+    if (c->world > 1 && c->comm && R->CommAbort) {
+      (void)R->CommAbort(c->comm);
+      c->comm = nullptr;
+    }
+    return rc;
   }
-  if (c->msg_cap < words) {
-    (void)hipStreamSynchronize(stream);
-    if (c->send) (void)hipFree(c->send);
-    if (c->recv) (void)hipFree(c->recv);
-    c->send = c->recv = nullptr;
-    c->msg_cap = 0;
-    EIOKU_HIP_CHECK(hipMalloc((void**)&c->send, words * sizeof(long long)));
-    EIOKU_HIP_CHECK(hipMalloc((void**)&c->recv, words * sizeof(long long) * (size_t)c->world));
-    c->msg_cap = words;
-  }
-  if (c->list_cap < (size_t)n * c->world) {
-    (void)hipStreamSynchronize(stream);
-    if (c->dl) (void)hipFree(c->dl);
-    if (c->il) (void)hipFree(c->il);
-    c->dl = nullptr;
-    c->il = nullptr;
-    c->list_cap = 0;
-    EIOKU_HIP_CHECK(hipMalloc((void**)&c->dl, (size_t)n * c->world * sizeof(float)));
-    EIOKU_HIP_CHECK(hipMalloc((void**)&c->il, (size_t)n * c->world * sizeof(long long)));
-    c->list_cap = (size_t)n * c->world;
-  }
-  // 1. this rank's shard (an empty shard answers with padding: FLT_MAX / -1, as FAISS pads)
-  int rc = eioku_index_search(ix, q, nq, k, c->Dloc, (int64_t*)c->Iloc, EIOKU_MEM_DEVICE, stream_);
-  if (rc != EIOKU_OK) return rc;
+  // 1. this rank's shard (an empty shard answers with padding: FLT_MAX / -1, as FAISS pads).  A search that fails
+  // locally must not strand the peers: this rank still sends a message - all padding - and returns its error after
+  // the collective, so the others complete (with this shard missing from their answer) and the caller sees the failure.
+  const int search_rc = eioku_index_search(ix, q, nq, k, c->Dloc, (int64_t*)c->Iloc, EIOKU_MEM_DEVICE, stream_);
+  char search_err[512] = "";
+  if (search_rc != EIOKU_OK) snprintf(search_err, sizeof search_err, "%s", eioku_last_error());
   // 2. one message per rank, one all-gather
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_pack_answer, dim3(blocks), dim3(256), 0, stream, c->Dloc, c->Iloc, n, id_base, c->send);
+  if (search_rc == EIOKU_OK)
+    hipLaunchKernelGGL(k_pack_answer, dim3(blocks), dim3(256), 0, stream, c->Dloc, c->Iloc, n, id_base, c->send);
+  else
+    hipLaunchKernelGGL(k_pad_answer, dim3(blocks), dim3(256), 0, stream, n, c->send);
   EIOKU_LAUNCH_CHECK();
   EIOKU_RCCL_CHECK(R->AllGather(c->send, c->recv, words, ncclInt64, c->comm, stream));
+  if (search_rc != EIOKU_OK) {
+    set_error("local shard search failed (the collective was completed with a padding message): %s", search_err);
+    return search_rc;
+  }
   // 3. local merge of world x k candidates per query: every rank ends with the same answer
   const unsigned ublocks = (unsigned)((n * c->world + 255) / 256);
   hipLaunchKernelGGL(k_unpack_answers, dim3(ublocks), dim3(256), 0, stream, c->recv, c->world, n, c->dl, c->il);

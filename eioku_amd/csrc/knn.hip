@@ -669,9 +669,12 @@ __global__ __launch_bounds__(64) void k_topk_merge_heads(const float* __restrict
 // overflows raises a device flag and the launch of the register-tile kernels that follows - gated on that flag -
 // recomputes the search (tested by forcing tiny lists).
 //
-// The products are ONE bf16 term, q.x ~ qh.xh (a third of the matrix work of the split-bf16 kernel above):
-// |q.x - qh.xh| <= (2^-8 + 2^-18) sum|q_i x_i| <= 2^-8 (1 + 2^-9) |q| |x| for round-to-nearest bf16 operands, so the
-// filter admits everything within that rigorous margin of tau_q; the distances that are returned never see bf16.
+// The products are ONE bf16 term, q.x ~ qh.xh (a third of the matrix work of the split-bf16 kernel above).  bf16 keeps 8
+// significant bits, so round-to-nearest has unit roundoff 2^-8 PER OPERAND: qh_i xh_i = q_i x_i (1 + a)(1 + b) with
+// |a|, |b| <= 2^-8, i.e. |q.x - qh.xh| <= (2^-7 + 2^-16) sum|q_i x_i| <= 2^-7 (1 + 2^-9) |q| |x|, and the filter admits
+// everything within that rigorous margin of tau_q (round 2 used half of it - ADVICE r2: a row just under a bf16
+// midpoint in every coordinate could be filtered out; tests/test_knn_scan_gpu.py holds that case now); the distances
+// that are returned never see bf16.
 //
 // Measured at 10 M x 384, nq 1024 (profiles/r02_knn_*): 7.4 ms for the scan = 1.06 PFLOP/s of algorithmic work;
 // ablation builds put the matrix-only floor of this structure at 4.85 ms, the filter at +1.5, the workgroup barrier
@@ -731,6 +734,7 @@ struct ScanArgs {
   const u32x4k* xh;      // [ntiles][NS*64] units
   const float* hnorm;    // [ntiles*32] 0.5 |x|^2, +inf beyond n
   const float* tmax;     // [ntiles] max |x| of the tile's valid rows
+  const float* xmax;     // [1] max |x| over all rows
   const u32x4k* qh;      // [nqt][NS*64]
   const float* qnorm;    // [nq]
   const float* tau;      // sample search result [nq][tau_k]; the bound is its last column
@@ -770,9 +774,12 @@ __global__ __launch_bounds__(NW * 64) void k_l2_scan(ScanArgs a) {
     if (q < a.nq) {
       const float t = a.tau[(size_t)q * a.tau_k + (a.tau_k - 1)];
       const float qn = a.qnorm[q];
-      // slack: the sample's distances come from another kernel (split-bf16 products, ~1e-6 absolute)
-      hc = 0.5f * (qn - (t + 2e-5f * (1.0f + t)));
-      sq = 0.00390625f * 1.002f * sqrtf(qn);  // 2^-8 (1 + 2^-9) |q|, rounded up
+      // slack: the sample's distances come from another kernel as |q|^2 + |x|^2 - 2 q.x in fp32 with split-bf16
+      // products, so their error scales with the NORMS (a few eps (|q| + |x|)^2), not with t: un-normalised rows with
+      // large norms and small distances need the second term
+      const float nrm = sqrtf(qn) + a.xmax[0];
+      hc = 0.5f * (qn - (t + 2e-5f * (1.0f + t) + 1e-6f * nrm * nrm));
+      sq = 0.0078125f * 1.002f * sqrtf(qn);  // 2^-7 (1 + 2^-9) |q|, rounded up
     }
     s_hc[q] = hc;
     s_sq[q] = sq;
@@ -1097,6 +1104,7 @@ struct eioku_index {
   unsigned char* xh = nullptr; size_t xhcap = 0;
   float* hnorm = nullptr; size_t hncap = 0;
   float* tmax = nullptr; size_t tmcap = 0;
+  float* xmax = nullptr;  // [1] max |x| over all rows (the norm-proportional slack of the scan's bound)
   long long planes_n = 0;      // rows covered by the plane
   unsigned char* qh = nullptr; size_t qhcap = 0;
   unsigned* wl = nullptr; size_t wlcap = 0;
@@ -1194,7 +1202,7 @@ void eioku_index_destroy(eioku_index* ix) {
   (void)hipDeviceSynchronize();
   if (ix->x && !ix->attached) (void)hipFree(ix->x);
   void* bufs[] = {ix->norms, ix->qbuf, ix->qnorm, ix->pd, ix->pi, ix->dout, ix->iout, ix->xh, ix->hnorm,
-                  ix->tmax, ix->qh, ix->wl, ix->wl_cnt, ix->tau, ix->tau_i, ix->tau1, ix->tau1_i, ix->cand_i, ix->cnt};
+                  ix->tmax, ix->xmax, ix->qh, ix->wl, ix->wl_cnt, ix->tau, ix->tau_i, ix->tau1, ix->tau1_i, ix->cand_i, ix->cnt};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete ix;
@@ -1404,6 +1412,20 @@ int grow_keep(T** p, size_t* cap, size_t bytes, size_t keep, hipStream_t stream)
   return EIOKU_OK;
 }
 
+__global__ __launch_bounds__(1024) void k_max_f32(const float* __restrict__ v, long long n, float* __restrict__ out) {
+  __shared__ float s_m[16];
+  float m = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, v[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, s_m[w]);
+    out[0] = m;
+  }
+}
+
 int ensure_planes(eioku_index* ix, hipStream_t stream) {
   const int d = ix->d;
   const size_t tile_b = (size_t)d * 32 * 2;  // bytes per 32-row tile
@@ -1418,6 +1440,9 @@ int ensure_planes(eioku_index* ix, hipStream_t stream) {
   if (ix->planes_n != ix->n) {
     rc = split_planes(d, ix->x, ix->n, keep_tiles, ntiles - keep_tiles, ix->norms, ix->xh, ix->hnorm, ix->tmax, false, stream);
     if (rc) return rc;
+    if (!ix->xmax) EIOKU_HIP_CHECK(hipMalloc((void**)&ix->xmax, sizeof(float)));
+    hipLaunchKernelGGL(k_max_f32, dim3(1), dim3(1024), 0, stream, ix->tmax, ntiles, ix->xmax);
+    EIOKU_LAUNCH_CHECK();
     ix->planes_n = ix->n;
   }
   return EIOKU_OK;
@@ -1523,6 +1548,7 @@ int scan_search(eioku_index* ix, const float* dq, int nq, int k, float* dD, long
   a.xh = (const u32x4k*)ix->xh;
   a.hnorm = ix->hnorm;
   a.tmax = ix->tmax;
+  a.xmax = ix->xmax;
   a.qh = (const u32x4k*)ix->qh;
   a.qnorm = ix->qnorm;
   a.tau = ix->tau;

@@ -18,6 +18,7 @@ from __future__ import annotations
 import multiprocessing as mp
 import os
 import sys
+import queue
 import time
 from dataclasses import dataclass, field
 
@@ -90,22 +91,47 @@ def run_node(jobs: list[Job], gpus: list[int], ctx_factory: str | None = None, w
         p.start()
         procs.append(p)
     out: list[dict | None] = [None] * len(jobs)
-    done = 0
+    finished = [False] * len(procs)      # the worker posted its (-1, gpu) sentinel, or it died
+    exit_codes: dict[int, int] = {}
     deadline = None if timeout is None else time.monotonic() + timeout
+    timed_out = False
     try:
-        while done < len(procs):
-            left = None if deadline is None else max(0.1, deadline - time.monotonic())
-            index, r = results.get(timeout=left)
+        while not all(finished):
+            # a short poll, not a blocking get: a worker that dies (GPU fault, OOM kill, segfault, a failed pin assert) never
+            # posts its sentinel, and with timeout=None the parent used to wait for it forever
+            try:
+                index, r = results.get(timeout=0.2)
+            except queue.Empty:
+                for i, p in enumerate(procs):
+                    if not finished[i] and not p.is_alive():
+                        try:  # whatever the dead worker still had in the pipe
+                            while True:
+                                index, r = results.get(timeout=0.05)
+                                if index < 0:
+                                    finished[gpus.index(r)] = True
+                                else:
+                                    out[index] = r
+                        except queue.Empty:
+                            pass
+                        finished[i] = True
+                        exit_codes[i] = p.exitcode if p.exitcode is not None else -1
+                if deadline is not None and time.monotonic() > deadline:
+                    timed_out = True
+                    break
+                continue
             if index < 0:
-                done += 1
+                finished[gpus.index(r)] = True
             else:
                 out[index] = r
     finally:
         for p in procs:
-            p.join(5)
+            p.join(5 if not timed_out else 0.1)
             if p.is_alive():
                 p.terminate()
-    for i, r in enumerate(out):
-        if r is None:
-            out[i] = {"task_id": jobs[i].task_id, "status": "failed", "error": "worker process died"}
+    for w, share in enumerate(shares):
+        for i in share:
+            if out[i] is None:
+                why = (f"worker process for GPU {gpus[w]} died (exit code {exit_codes[w]})" if w in exit_codes
+                       else "timed out" if timed_out else "worker process died")
+                out[i] = {"task_id": jobs[i].task_id, "status": "failed", "error": why, "gpu": gpus[w]}
     return out  # type: ignore[return-value]

@@ -147,8 +147,11 @@ class VectorStore:
         return np.stack(self._rows).astype(np.float32) if self._rows else np.zeros((0, self.d), np.float32)
 
     def search(self, query_embedding, top_k: int = 10, filters: dict | None = None) -> list[tuple[float, dict]]:
-        """``[(squared L2 distance, metadata)]`` ascending.  ``filters``: ``{"video_id": id or [ids]}`` - applied to an
-        over-fetched result list (at most 32 nearest), so a narrow filter can return fewer than ``top_k``."""
+        """``[(squared L2 distance, metadata)]`` ascending, up to ``top_k`` entries (any ``top_k``: rounds of 32 chained by
+        ``IndexFlatL2.search_many``).  ``filters``: ``{"video_id": id or [ids]}``; the fetch grows until ``top_k`` rows of
+        the wanted videos are found or the index is exhausted, so a narrow filter still returns what the videos hold."""
+        if top_k < 1:
+            raise ValueError(f"top_k must be >= 1, got {top_k}")
         if not self._meta:
             return []
         if self._index is None:
@@ -157,23 +160,27 @@ class VectorStore:
             self._index = IndexFlatL2(self.d)
             self._index.add(self.matrix())
         q = np.asarray(query_embedding, dtype=np.float32).reshape(1, self.d)
-        fetch = min(32, max(top_k, 32 if filters else top_k))
-        D, I = self._index.search(q, fetch)
         allowed = None
         if filters and filters.get("video_id") is not None:
             v = filters["video_id"]
             allowed = set(v) if isinstance(v, (list, tuple, set)) else {v}
-        out = []
-        for dist, i in zip(D[0], I[0]):
-            if i < 0:
-                break
-            m = self._meta[int(i)]
-            if allowed is not None and m.get("video_id") not in allowed:
-                continue
-            out.append((float(dist), m))
-            if len(out) == top_k:
-                break
-        return out
+        n = len(self._meta)
+        fetch = min(n, top_k if allowed is None else max(32, 4 * top_k))
+        while True:
+            D, I = self._index.search_many(q, fetch)
+            out = []
+            for dist, i in zip(D[0], I[0]):
+                if i < 0:
+                    break
+                m = self._meta[int(i)]
+                if allowed is not None and m.get("video_id") not in allowed:
+                    continue
+                out.append((float(dist), m))
+                if len(out) == top_k:
+                    break
+            if len(out) == top_k or fetch >= n:
+                return out
+            fetch = min(n, fetch * 4)
 
     # ---- the .index file -----------------------------------------------------------------------------
     def save(self, path: str | Path) -> None:

@@ -53,3 +53,47 @@ def test_real_worker_pins_before_importing_the_gpu_stack(tmp_path):
     jobs = [ingest.Job("t0", "scene_detection", "v0", str(tmp_path / "missing.npy"), {})]
     out = ingest.run_node(jobs, [5], timeout=120)
     assert out[0]["status"] == "failed" and out[0]["gpu"] == 5 and "Failed to process task t0" in out[0]["error"]
+
+
+def _dying_worker(gpu, jobs, results, ctx_factory, extra_env):
+    """GPU 1's worker finishes one job, then dies without posting its sentinel (GPU fault / OOM kill / segfault)."""
+    for n, (index, job) in enumerate(jobs):
+        if gpu == 1 and n == 1:
+            import time
+
+            time.sleep(1.0)  # the queue's feeder thread has flushed the first result by now
+            os._exit(9)
+        results.put((index, {"task_id": job.task_id, "status": "completed", "gpu": gpu}))
+    results.put((-1, gpu))
+
+
+def test_a_worker_that_dies_does_not_hang_the_node_or_lose_the_others_results():
+    """with timeout=None the parent used to block forever in results.get(); with a timeout
+    queue.Empty escaped and the healthy workers' results were lost."""
+    jobs = _jobs([1] * 6)
+    out = ingest.run_node(jobs, [0, 1], worker=_dying_worker, timeout=None)
+    shares = ingest.plan(jobs, 2)
+    assert [r["task_id"] for r in out] == [f"t{i}" for i in range(6)]
+    for i in shares[0]:
+        assert out[i]["status"] == "completed" and out[i]["gpu"] == 0
+    assert out[shares[1][0]]["status"] == "completed"              # what the worker finished before it died is kept
+    for i in shares[1][1:]:
+        assert out[i]["status"] == "failed" and "exit code 9" in out[i]["error"] and out[i]["gpu"] == 1
+
+
+def _slow_worker(gpu, jobs, results, ctx_factory, extra_env):
+    import time
+
+    for index, job in jobs:
+        if gpu == 1:
+            time.sleep(30)
+        results.put((index, {"task_id": job.task_id, "status": "completed", "gpu": gpu}))
+    results.put((-1, gpu))
+
+
+def test_deadline_returns_the_partial_results():
+    jobs = _jobs([1] * 4)
+    out = ingest.run_node(jobs, [0, 1], worker=_slow_worker, timeout=3)
+    shares = ingest.plan(jobs, 2)
+    assert all(out[i]["status"] == "completed" for i in shares[0])
+    assert all(out[i]["status"] == "failed" and out[i]["error"] == "timed out" for i in shares[1])

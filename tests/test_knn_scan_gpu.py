@@ -205,3 +205,56 @@ def test_full_size_10m_scan_equals_register_tile_search(gpu):
     err = (D[60:76].double() - best.clamp(min=0)).abs()
     assert bool((err <= 5e-6 + 1e-4 * best.abs()).all()), float(err.max())
     ix.close()
+
+
+@pytest.mark.parametrize("rt", [1, 2])
+def test_rows_just_under_bf16_midpoints_are_never_filtered_out(gpu, rt):
+    """the scan's filter margin must cover round-to-nearest bf16 on BOTH operands:
+    |q.x - bf(q).bf(x)| <= (2^-7 + 2^-16) sum|q_i x_i|.  q = x = 1.0039053 in every coordinate sits just under a bf16
+    rounding midpoint (bf16 spacing at 1.0 is 2^-7): the bf16 product is 384.0 against a true 387.02, so with half that
+    margin (round 2) the exact copy was filtered out whenever the bound tau was below ~2.98.  400 rows are
+    near-duplicates of the query (distance^2 ~ 0.15): the sample and the pre-scan make tau small, the copy must
+    still come back first at distance exactly 0, and so must unnormalised near-midpoint rows of other signs."""
+    n, d, k = 60000, 384, 10
+    rng = np.random.default_rng(41)
+    base = np.full((d,), 1.0039053, dtype=np.float32)
+    sign = np.where(np.arange(d) % 3 == 0, -1.0, 1.0).astype(np.float32)
+    xb = (3.0 * rng.standard_normal((n, d))).astype(np.float32)                 # far rows
+    near = rng.choice(n, 400, replace=False)  # enough for the sample (>= 32768 rows) to hold k of them, few enough for the candidate lists
+    xb[near] = base + 0.02 * rng.standard_normal((len(near), d)).astype(np.float32)
+    near2 = near[: len(near) // 2]
+    xb[near2] = sign * xb[near2]
+    xb[near[0]] = base * sign                                                   # the exact copies
+    xb[near[-1]] = base
+    xq = np.stack([base, base * sign, 2.0 * base]).astype(np.float32)           # 2 x base: also midpoints, no copy
+    ix = scan_index(d, scan_rt=rt)
+    ix.add(xb)
+    D, I = ix.search(xq, k)
+    Dt, It = oknn.search(xb, xq, k)
+    assert I[0, 0] == near[-1] and D[0, 0] == 0.0
+    assert I[1, 0] == near[0] and D[1, 0] == 0.0
+    check(D, I, Dt, It, xb, xq)
+    ix.close()
+
+
+def test_large_norm_rows_with_small_distances(gpu):
+    """the bound's slack must scale with the norms (the sample's distances are |q|^2 + |x|^2 - 2 q.x in
+    fp32, absolute error ~1e-3 at norm 100): rows of norm ~100 whose true nearest distances are ~2.6e-2."""
+    n, d, k = 50000, 128, 10
+    rng = np.random.default_rng(43)
+    centre = (100.0 / np.sqrt(d)) * np.ones((d,), np.float32)
+    # far rows at distance^2 ~ 1150: beyond the filter's margin, which scales with the norms (2 x 2^-7 |q| |x| ~ 160 here)
+    xb = (centre + 3.0 * rng.standard_normal((n, d))).astype(np.float32)
+    near = rng.choice(n, 300, replace=False)
+    xb[near] = centre + 0.01 * rng.standard_normal((300, d)).astype(np.float32)  # distance^2 ~ 0.026: tau is tiny
+    xb[123] = centre + 0.01 * rng.standard_normal(d).astype(np.float32)
+    xq = (centre + 0.01 * rng.standard_normal((16, d))).astype(np.float32)
+    xq[0] = xb[123]
+    ix = scan_index(d)
+    ix.add(xb)
+    D, I = ix.search(xq, k)
+    Dt, It = oknn.search(xb, xq, k)
+    assert I[0, 0] == 123 and D[0, 0] == 0.0
+    # ids exact wherever the float64 truth separates them; distances to 1e-4 relative
+    check(D, I, Dt, It, xb, xq)
+    ix.close()

@@ -116,3 +116,27 @@ def test_segment_embedding_task_and_semantic_search_end_to_end(gpu, vocab_file, 
     assert engine2.search_dicts("guitar solo music", top_k=2) == engine.search_dicts("guitar solo music", top_k=2)
     with pytest.raises(RuntimeError, match="needs config"):
         asyncio.run(task_handler.process_ml_task(ctx, "t4", "segment_embedding", "vidC", "/videos/c.mp4", {}))
+
+
+@pytest.mark.gpu
+def test_vector_store_serves_large_top_k_and_narrow_filters(gpu):
+    """top_k > 32 used to be clamped to 32 silently, and a video_id filter only saw the 32 global nearest
+    (a video whose segments are not among them returned nothing)."""
+    rng = np.random.default_rng(5)
+    st = semantic.VectorStore(384)
+    x = rng.standard_normal((300, 384)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    q = x[0] + 0.01 * rng.standard_normal(384).astype(np.float32)
+    # video "far" owns the 60 rows FARTHEST from q: none of them is among the 32 global nearest
+    order = np.argsort(((x - q) ** 2).sum(1))
+    far = set(order[-60:].tolist())
+    for i in range(300):
+        st.index_segment(f"s{i}", x[i], {"video_id": "far" if i in far else "near", "row": i})
+    got = st.search(q, top_k=100)
+    assert len(got) == 100 and [m["row"] for _, m in got] == order[:100].tolist()
+    assert all(a[0] <= b[0] for a, b in zip(got, got[1:]))
+    only_far = st.search(q, top_k=40, filters={"video_id": "far"})
+    assert len(only_far) == 40 and [m["row"] for _, m in only_far] == order[-60:-20].tolist()
+    assert len(st.search(q, top_k=500, filters={"video_id": ["far"]})) == 60  # all the video has
+    with pytest.raises(ValueError):
+        st.search(q, top_k=0)
