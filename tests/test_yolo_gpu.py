@@ -192,12 +192,18 @@ def test_nms_keeps_at_most_max_det_and_suppresses_duplicates(gpu):
     ("n", 1, 480, 854, 5, 20),      # BASELINE cfg1's 480p clip
     ("m", 80, 1080, 1920, 6, 3),    # cfg4's object model: a deeper random net leaves fewer margin-decided detections
 ])
-def test_detect_end_to_end_exact_on_margin_stable_detections(gpu, variant, nc, h, w, seed, min_stable):
+@pytest.mark.parametrize("oracle_fp16", [True, False], ids=["vs_fp16_oracle", "vs_fp32_reference_precision"])
+def test_detect_end_to_end_exact_on_margin_stable_detections(gpu, variant, nc, h, w, seed, min_stable, oracle_fp16):
     """detect() end to end (letterbox -> network -> decode -> NMS -> scale_boxes) against the oracle, BASELINE's bar:
     post-NMS indices exact.  Scope: the margin-stable detections of tests/wellcond.py, with the drift bounds MEASURED
     in this run (oracle decode of the HIP head maps vs of the oracle head maps) and doubled.  Both directions: what
     the oracle keeps stably the HIP path keeps, and what the HIP path keeps stably (judged on ITS maps) the oracle
-    keeps; same class; and the stable anchors appear in the same order on both sides."""
+    keeps; same class; and the stable anchors appear in the same order on both sides.
+
+    oracle_fp16 = False: the oracle is the fp32 network - the reference's own precision
+    (model_manager.py:270-291: Ultralytics predicts with half=False) - so the drift is fp16-build vs reference
+    arithmetic; it is measured the same way and doubled, the assertions are the same, the floor on the number of
+    margin-stable detections is lower (>= 10 per frame for v8n / face) because the margins are wider."""
     conf = 0.25
     frames = wellcond.blob_frames(seed, 1, h, w)
     state = wellcond.calibrated_state(frames, variant, nc, seed=7, frac=0.08, conf=conf)
@@ -205,14 +211,17 @@ def test_detect_end_to_end_exact_on_margin_stable_detections(gpu, variant, nc, h
     dets, counts = det.detect(_dev(frames, gpu), conf=conf)
     dets_h, counts_h = det.detect(frames, conf=conf)  # host staging path gives the same bytes
     assert np.array_equal(counts, counts_h) and np.array_equal(dets, dets_h)
-    net = oy.Net(state, *W.YOLO_VARIANTS[variant], nc)
+    net = oy.Net(state, *W.YOLO_VARIANTS[variant], nc, fp16=oracle_fp16)
     ref, (_, _, boxes_o, scores_o) = oy.detect(net, frames, conf)
+    if not oracle_fp16:
+        min_stable = 10 if variant == "n" else 3  # measured: 18-41 (v8n / face), 14 (v8m)
     # the HIP side's own head maps, decoded by the oracle: its view of every anchor
     x, plan = D.letterbox_f16(_dev(frames, gpu))
     hb, hc = det.forward_raw(x)
     boxes_g, scores_g = oy.decode([t.cpu().numpy() for t in hb], [t.cpu().numpy() for t in hc])
     dc, du = wellcond.drift(boxes_o[0], scores_o[0], boxes_g[0], scores_g[0], conf)
-    assert dc < 0.03 and du < 0.08, (dc, du)  # the network tolerance (HEAD_MAX) seen through sigmoid / IoU
+    # the network tolerance (HEAD_MAX / FP32_MAX) seen through sigmoid / IoU
+    assert (dc < 0.03 and du < 0.08) if oracle_fp16 else (dc < 0.04 and du < 0.08), (dc, du)
     dc, du = 2 * dc + 1e-6, 2 * du + 1e-6
     k = int(counts[0])
     got = [int(a) for a in dets["anchor"][0, :k]]
@@ -225,7 +234,11 @@ def test_detect_end_to_end_exact_on_margin_stable_detections(gpu, variant, nc, h
         assert got == [a for a, *_ in ref_g[0]]
     stable_o = wellcond.stably_kept(boxes_o[0], scores_o[0], want, conf, dc, du)
     stable_g = wellcond.stably_kept(boxes_g[0], scores_g[0], got, conf, dc, du)
-    assert len(stable_o) >= min_stable and len(stable_g) >= min_stable, (len(stable_o), len(stable_g), len(want), dc, du)
+    report = (f"margin-stable: {len(stable_o)} of the oracle's {len(want)} detections ({len(stable_o) / max(len(want), 1):.0%}), "
+              f"{len(stable_g)} of the HIP path's {len(got)}; drift bounds used: conf {dc:.4f}, IoU {du:.4f}; "
+              f"oracle {'fp16' if oracle_fp16 else 'fp32'}")
+    print(report)
+    assert len(stable_o) >= min_stable and len(stable_g) >= min_stable, report
     assert [a for a in stable_o if a not in got] == [], "a margin-stable oracle detection is missing from the HIP result"
     assert [a for a in stable_g if a not in want] == [], "a margin-stable HIP detection is missing from the oracle result"
     both = [a for a in stable_o if a in set(stable_g)]
