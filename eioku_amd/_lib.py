@@ -45,6 +45,14 @@ SIGNATURES = {
                                        C.c_void_p, C.c_int, C.c_void_p]),
     "eioku_scene_sad_luma_bgr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_void_p]),
+    "eioku_scene_scores_from_sad": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "eioku_scene_scores_luma": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_double,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "eioku_scene_content_scores": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]),
+    "eioku_scene_content_cuts": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                           C.POINTER(C.c_int)]),
+    "eioku_scene_content": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p]),
     "eioku_bgr2hsv": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "eioku_conv2d_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -115,6 +123,20 @@ SIGNATURES = {
     "eioku_ivfpq_scan_tables": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eioku_resnet18_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "eioku_resnet18_destroy": (None, [C.c_void_p]),
+    "eioku_resnet18_num_convs": (C.c_int, [C.c_void_p]),
+    "eioku_resnet18_conv_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "eioku_resnet18_set_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "eioku_resnet18_set_fc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eioku_places_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "eioku_resnet18_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "eioku_resnet18_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p]),
+    "eioku_resnet18_last_flops": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "eioku_ivfpq_lists_aux": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eioku_ivfpq_lists_workspace": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int]),

@@ -36,7 +36,9 @@ int conv_weights_create(ConvWeights* cw, int cout, int cin, int ks, int stride, 
                         const float* b);
 void conv_weights_destroy(ConvWeights* cw);
 
-enum ConvAct { kActNone = 0, kActSiLU = 1 };
+// kActReLU: relu(conv + bias) [then + res]; kActResReLU: relu(fp16(conv + bias) + res) - the torchvision BasicBlock's
+// order (the activation follows the residual sum); the two ReLU modes serve the ResNet18 of classify_places
+enum ConvAct { kActNone = 0, kActSiLU = 1, kActReLU = 2, kActResReLU = 3 };
 
 // out = act(conv(in) + bias) [+ res]; output fp16 into `out`, or fp32 into `out_f32` (dense
 // [N,Ho,Wo,cout]) when out_f32 != nullptr.  H, W: input size; output is ceil-free standard

@@ -98,6 +98,8 @@ __device__ __forceinline__ float4v activate_frag(const ConvArgs& a, const float4
   float4v v = acc + float4v{b.x, b.y, b.z, b.w};
   if (a.act == kActSiLU) {
     v = silu4(v);
+  } else if (a.act == kActReLU) {
+    v = __builtin_elementwise_max(v, float4v{0.f, 0.f, 0.f, 0.f});
   }
   return v;
 }
@@ -109,6 +111,8 @@ __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc
   float4v v = acc + float4v{b.x, b.y, b.z, b.w};
   if (a.act == kActSiLU) {
     v = silu4(v);
+  } else if (a.act == kActReLU) {
+    v = __builtin_elementwise_max(v, float4v{0.f, 0.f, 0.f, 0.f});
   }
   const bool full = c0 + 3 < a.Cout;
   if (a.out_f32) {
@@ -126,7 +130,8 @@ __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc
   if (full) {
     if (a.res) {
       const u32x2 r = have_rpre ? rpre : *reinterpret_cast<const u32x2*>(a.res + opix * a.res_cs + c0);
-      const float4v sum = __builtin_convertvector(h, float4v) + __builtin_convertvector(__builtin_bit_cast(f16x4, r), float4v);
+      float4v sum = __builtin_convertvector(h, float4v) + __builtin_convertvector(__builtin_bit_cast(f16x4, r), float4v);
+      if (a.act == kActResReLU) sum = __builtin_elementwise_max(sum, float4v{0.f, 0.f, 0.f, 0.f});
       h = __builtin_convertvector(sum, f16x4);
     }
     *reinterpret_cast<u32x2*>(a.out + opix * a.out_cs + c0) = __builtin_bit_cast(u32x2, h);
@@ -135,7 +140,11 @@ __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc
     for (int j = 0; j < 4; ++j)
       if (c0 + j < a.Cout) {
         _Float16 o = h[j];
-        if (a.res) o = (_Float16)((float)o + __half2float(a.res[opix * a.res_cs + c0 + j]));
+        if (a.res) {
+          float sj = (float)o + __half2float(a.res[opix * a.res_cs + c0 + j]);
+          if (a.act == kActResReLU) sj = fmaxf(sj, 0.f);
+          o = (_Float16)sj;
+        }
         reinterpret_cast<_Float16*>(a.out)[opix * a.out_cs + c0 + j] = o;
       }
   }
@@ -2358,7 +2367,8 @@ int eioku_conv2d_f16(const void* in_nhwc, int n, int h, int w, int in_cstride, i
   Slice in{(__half*)in_nhwc, in_cstride, in_coff};
   Slice out{(__half*)out_nhwc, out_cstride, out_coff};
   Slice res{(__half*)residual, res_cstride, res_coff};
-  rc = conv_forward(cw, in, n, h, w, out, out_f32, res, act_silu ? kActSiLU : kActNone, stream);
+  const int act = act_silu == 1 ? kActSiLU : act_silu == 2 ? kActReLU : act_silu == 3 ? kActResReLU : kActNone;
+  rc = conv_forward(cw, in, n, h, w, out, out_f32, res, act, stream);
   if (rc == EIOKU_OK) {
     hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess) {

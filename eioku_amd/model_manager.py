@@ -33,7 +33,7 @@ class ModelManager:
     """Manages model lifecycle and inference for the hot-path task types."""
 
     def __init__(self, cache_dir: str = "/models", *, frame_source=None, detector_factory=None, batch_size: int = 64,
-                 random_init_seed: int | None = None):
+                 random_init_seed: int | None = None, place_classifier_factory=None):
         """``cache_dir`` as in the reference (:12-21).  Keyword-only extras are seams for tests and bench:
         ``frame_source(path) -> FrameSource``, ``detector_factory(model_name, cache_dir) -> detector`` with
         ``detect(frames, conf=...) -> (dets, counts)`` and ``names``; ``random_init_seed`` builds random
@@ -44,6 +44,7 @@ class ModelManager:
         self._gpu_available = None  # Lazy initialization
         self._frame_source = frame_source
         self._detector_factory = detector_factory
+        self._place_classifier_factory = place_classifier_factory  # (cache_dir) -> object with classify(frames, top_k), labels
         self._batch_size = int(batch_size)
         self._seed = random_init_seed
 
@@ -96,9 +97,6 @@ class ModelManager:
 
     async def extract_ocr(self, video_path: str, config: dict) -> dict:
         raise NotImplementedError(f"extract_ocr {OUT_OF_SCOPE}")
-
-    async def classify_places(self, video_path: str, config: dict) -> dict:
-        raise NotImplementedError(f"classify_places {OUT_OF_SCOPE}")
 
     async def extract_metadata(self, video_path: str, config: dict) -> dict:
         raise NotImplementedError(f"extract_metadata {OUT_OF_SCOPE}")
@@ -206,6 +204,75 @@ class ModelManager:
             if close:
                 close()
         return detections
+
+    # ---- places: Places365 ResNet18 (reference :560-713) ---------------------------------------------------
+    def _load_place_classifier(self):
+        """``models.resnet18`` + 365-way fc + ``<cache>/places365/resnet18_places365.pth.tar`` and the label file
+        (ref :579-624), per job like the reference."""
+        if self._place_classifier_factory is not None:
+            return self._place_classifier_factory(self.cache_dir)
+        from .places import Places365Classifier
+
+        return Places365Classifier.from_cache(self.cache_dir, seed=self._seed)
+
+    async def classify_places(self, video_path: str, config: dict) -> dict:
+        """Classify places in video frames using Places365 on the HIP path (reference: :560-713): every
+        ``max(1, int(fps * frame_interval))``-th frame -> softmax top_k ``{"label", "confidence"}`` lists."""
+        try:
+            logger.info(f"Place detection: {video_path} (device: {self._get_device()})")
+            classifier = self._load_place_classifier()
+            classes = classifier.labels
+            cap = self._open(video_path)
+            fps = cap.fps or 30
+            total_frames = int(cap.total_frames)
+            frame_interval_seconds = config.get("frame_interval", 1)
+            top_k = config.get("top_k", 5)
+            frame_interval = max(1, int(fps * frame_interval_seconds))
+            frames_to_process = (total_frames + frame_interval - 1) // frame_interval
+            logger.info(f"Video FPS: {fps}, Total frames: {total_frames}, Processing every {frame_interval} frames "
+                        f"(every {frame_interval_seconds}s, ~{frames_to_process} frames to process)")
+            classifications: list[dict] = []
+            pend_frames: list[np.ndarray] = []
+            pend_meta: list[tuple[int, int]] = []
+
+            def flush():
+                if not pend_frames:
+                    return
+                probs, idx = classifier.classify(np.stack(pend_frames), top_k)
+                for (frame_idx, timestamp_ms), p, i in zip(pend_meta, probs, idx):
+                    # `for j, i in enumerate(idx[:top_k])`: float(probs[j]) widens the float32 (ref :677-683)
+                    classifications.append({"frame_index": frame_idx, "timestamp_ms": timestamp_ms,
+                                            "predictions": [{"label": classes[int(c)], "confidence": float(np.float32(v))}
+                                                            for v, c in zip(p, i)]})
+                pend_frames.clear()
+                pend_meta.clear()
+
+            frame_idx = 0
+            try:
+                while True:
+                    if frame_idx % frame_interval == 0:
+                        ret, frame = cap.read()
+                        if not ret:
+                            break
+                        pend_frames.append(frame)
+                        pend_meta.append((frame_idx, int((frame_idx / fps) * 1000)))
+                        if len(pend_frames) >= self._batch_size:
+                            flush()
+                    else:
+                        if not cap.grab():
+                            break
+                    frame_idx += 1
+                flush()
+            finally:
+                cap.release()
+                close = getattr(classifier, "close", None)
+                if close:
+                    close()
+            logger.info(f"✅ Place detection complete: {len(classifications)} classifications")
+            return {"classifications": classifications}
+        except Exception as e:
+            logger.error(f"Place detection failed: {e}", exc_info=True)
+            raise
 
     async def detect_objects(self, video_path: str, config: dict) -> dict:
         """Detect objects in video using YOLOv8 on the HIP path (reference: :215-306)."""

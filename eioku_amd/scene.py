@@ -84,6 +84,40 @@ def luma_sad_bgr(bgr_frames, prev=None, *, keep_on_device: bool = False) -> np.n
     return _finish(out, keep_on_device)
 
 
+def scene_scores_luma(y_frames, prev=None, prev_mafd: float = 0.0):
+    """K1 + libavfilter's score in one C call (``eioku_scene_scores_luma``): ``(mafd, score)`` float64 arrays for
+    ``(n,h,w)`` uint8 luma planes (numpy: staged; CUDA tensor: zero copy).  Synchronises the stream."""
+    lib = _lib.load()
+    _lib.init()
+    n, h, w = (int(s) for s in y_frames.shape)
+    mafd = np.zeros(n, np.float64)
+    score = np.zeros(n, np.float64)
+    _lib.check(lib.eioku_scene_scores_luma(ptr(y_frames), n, h, w, w, h * w, ptr(prev), float(prev_mafd), ptr(mafd), ptr(score),
+                                           same_side(y_frames, prev), current_stream(y_frames)), "eioku_scene_scores_luma")
+    return mafd, score
+
+
+def content_detect(bgr_frames, prev=None, threshold: float = 27.0, min_scene_len: int = 15, mode: str = "legacy"):
+    """ContentDetector end to end in one C call (``eioku_scene_content``): ``(cut frame indices, scores)`` for
+    ``(n,h,w,3)`` BGR frames.  Synchronises the stream."""
+    import ctypes as C
+
+    if mode not in ("legacy", "suppress", "merge"):
+        raise ValueError(f"unknown mode {mode!r}")
+    lib = _lib.load()
+    _lib.init()
+    n, h, w, c = (int(s) for s in bgr_frames.shape)
+    if c != 3:
+        raise ValueError("expected (n,h,w,3) BGR frames")
+    cuts = np.zeros(max(n, 1), np.int32)
+    scores = np.zeros(n, np.float64)
+    found = C.c_int(0)
+    _lib.check(lib.eioku_scene_content(ptr(bgr_frames), n, h, w, ptr(prev), float(threshold), int(min_scene_len),
+                                       1 if mode == "merge" else 0, ptr(cuts), n, C.byref(found), ptr(scores),
+                                       same_side(bgr_frames, prev), current_stream(bgr_frames)), "eioku_scene_content")
+    return [int(t) for t in cuts[:found.value]], scores
+
+
 def bgr2hsv(bgr):
     """OpenCV-compatible 8-bit BGR->HSV image (parity/debug helper)."""
     lib = _lib.load()
@@ -109,20 +143,16 @@ def ffmpeg_scene_scores(sad: np.ndarray, count: int, *, bitdepth: int = 8, prev_
     """libavfilter ``get_scene_score`` on the SAD series -> ``(mafd, score)`` float64 arrays.
 
     ``mafd = sad / count / 2**(bitdepth-8)``; ``score = clip(float32(min(mafd, |mafd - prev|) / 100))``
-    (the value passes through ``av_clipf``, i.e. is rounded to float32).
+    (the value passes through ``av_clipf``, i.e. is rounded to float32).  The arithmetic lives behind the C ABI
+    (``eioku_scene_scores_from_sad``, csrc/scene_host.hip): one implementation for every binder.
     """
-    sad = np.asarray(sad, dtype=np.uint64)
-    mafd = sad.astype(np.float64) / float(count) / float(1 << (bitdepth - 8))
-    prev = np.concatenate(([float(prev_mafd)], mafd[:-1]))
-    q = np.minimum(mafd, np.abs(mafd - prev)) / 100.0
-    score = np.clip(q.astype(np.float32), np.float32(0), np.float32(1)).astype(np.float64)
-    if not first_has_prev and len(score):
-        mafd = mafd.copy()
-        mafd[0] = 0.0
-        score[0] = 0.0
-        if len(score) > 1:  # prev_mafd for frame 1 is still the zero initialisation
-            q1 = min(mafd[1], abs(mafd[1] - float(prev_mafd))) / 100.0
-            score[1] = float(np.clip(np.float32(q1), np.float32(0), np.float32(1)))
+    sad = np.ascontiguousarray(sad, dtype=np.uint64)
+    n = len(sad)
+    mafd = np.zeros(n, np.float64)
+    score = np.zeros(n, np.float64)
+    _lib.check(_lib.load().eioku_scene_scores_from_sad(ptr(sad), n, float(count), int(bitdepth), float(prev_mafd),
+                                                       int(bool(first_has_prev)), ptr(mafd), ptr(score)),
+               "eioku_scene_scores_from_sad")
     return mafd, score
 
 
@@ -132,63 +162,33 @@ def pts_time_string(frame_index: int, tb_num: int, tb_den: int, pts_per_frame: i
 
 
 def content_scores(sums: np.ndarray, num_pixels: int, *, first_has_prev: bool = False) -> np.ndarray:
-    """ContentDetector frame score: ``(dh + ds + dl + 0.0) / 3.0`` with ``d = sum / float(pixels)``."""
-    s = np.asarray(sums, dtype=np.uint64).astype(np.float64) / float(num_pixels)
-    acc = 0.0 + s[:, 0] * 1.0
-    acc = acc + s[:, 1] * 1.0
-    acc = acc + s[:, 2] * 1.0
-    acc = acc + 0.0 * 0.0
-    out = acc / 3.0
-    if not first_has_prev and len(out):
-        out[0] = 0.0
+    """ContentDetector frame score: ``(dh + ds + dl + 0.0) / 3.0`` with ``d = sum / float(pixels)``
+    (``eioku_scene_content_scores``)."""
+    sums = np.ascontiguousarray(sums, dtype=np.uint64).reshape(-1, 3)
+    out = np.zeros(len(sums), np.float64)
+    _lib.check(_lib.load().eioku_scene_content_scores(ptr(sums), len(sums), float(num_pixels), int(bool(first_has_prev)), ptr(out)),
+               "eioku_scene_content_scores")
     return out
 
 
 def content_cuts(scores, threshold: float = 27.0, min_scene_len: int = 15, mode: str = "legacy") -> list[int]:
-    """Cut frames from ContentDetector scores.
+    """Cut frames from ContentDetector scores (``eioku_scene_content_cuts``).
 
     ``legacy``: PySceneDetect 0.6.0-0.6.3 rule (``score >= threshold`` and ``min_scene_len`` frames
     since the last cut, counting from the first frame); ``suppress`` is the same rule under its
     0.6.4+ name; ``merge``: the 0.6.4+ ``FlashFilter.Mode.MERGE`` state machine.
     """
-    scores = np.asarray(scores, dtype=np.float64)
-    n = len(scores)
-    above = scores >= threshold
-    if n:
-        above[0] = False
-    cuts: list[int] = []
-    if mode in ("legacy", "suppress"):
-        last = 0
-        for t in np.nonzero(above)[0]:
-            if t - last >= min_scene_len:
-                cuts.append(int(t))
-                last = int(t)
-        return cuts
-    if mode != "merge":
+    import ctypes as C
+
+    if mode not in ("legacy", "suppress", "merge"):
         raise ValueError(f"unknown mode {mode!r}")
-    if min_scene_len <= 0:
-        return [int(t) for t in np.nonzero(above)[0]]
-    last_above = 0  # the filter first sees frame 0
-    enabled = triggered = False
-    start = 0
-    for t in range(n):
-        met = (t - last_above) >= min_scene_len
-        if above[t]:
-            last_above = t
-        if triggered:
-            if met and not above[t] and (last_above - start) >= min_scene_len:
-                triggered = False
-                cuts.append(last_above)
-            continue
-        if not above[t]:
-            continue
-        if met:
-            enabled = True
-            cuts.append(t)
-        elif enabled:
-            triggered = True
-            start = t
-    return cuts
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    n = len(scores)
+    cuts = np.zeros(max(n, 1), np.int32)
+    found = C.c_int(0)
+    _lib.check(_lib.load().eioku_scene_content_cuts(ptr(scores), n, float(threshold), int(min_scene_len), 1 if mode == "merge" else 0,
+                                                    ptr(cuts), n, C.byref(found)), "eioku_scene_content_cuts")
+    return [int(t) for t in cuts[:found.value]]
 
 
 def build_scenes(cut_timestamps_ms, duration_ms: int | None) -> list[dict]:

@@ -27,9 +27,10 @@ from uuid import uuid4
 logger = logging.getLogger(__name__)
 
 TASK_TO_ARTIFACT_TYPE = {"object_detection": "object.detection", "face_detection": "face.detection",
-                         "scene_detection": "scene", "segment_embedding": "segment.embedding"}
+                         "scene_detection": "scene", "segment_embedding": "segment.embedding",
+                         "place_detection": "place.classification"}
 TASK_TO_RESULT_KEY = {"object_detection": "detections", "face_detection": "detections", "scene_detection": "scenes",
-                      "segment_embedding": "embeddings"}
+                      "segment_embedding": "embeddings", "place_detection": "classifications"}
 # the reference's seven (task_handler.py:92-127) + the one its semantic-search design adds after transcription
 # (.kiro/specs/semantic-video-search/tasks.md:297-302): embed the transcript segments, index them
 KNOWN_TASK_TYPES = ("object_detection", "face_detection", "transcription", "ocr", "place_detection",
@@ -152,6 +153,8 @@ async def process_ml_task(ctx, task_id: str, task_type: str, video_id: str, vide
             result = await model_manager.detect_faces(video_path, config or {})
         elif task_type == "scene_detection":
             result = await model_manager.detect_scenes(video_path, config or {})
+        elif task_type == "place_detection":
+            result = await model_manager.classify_places(video_path, config or {})
         elif task_type == "segment_embedding":
             # segments: the transcription task's output for this video.  The reference would read them back from its
             # artifact table; without a database they arrive in the job config or through ctx["segment_source"](video_id)

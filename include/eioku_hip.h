@@ -113,6 +113,28 @@ int eioku_scene_hsv_sums(const uint8_t* bgr_frames, int n, int h, int w, size_t 
 int eioku_scene_sad_luma_bgr(const uint8_t* bgr_frames, int n, int h, int w, size_t frame_stride, const uint8_t* prev,
                              uint64_t* sad_out, int mem, void* stream);
 
+/* ---- scene scores and cut rules (host arithmetic behind the ABI; csrc/scene_host.hip) ----
+ * What the reference reads from its ffmpeg child (`select='gt(scene,T)'`: /root/reference/ml-service/src/services/
+ * model_manager.py:736-786) and the ContentDetector the north star names, restated once, in the libraries' own float
+ * order, so that a binder in any language gets the bits eioku_amd/scene.py gets.  Outputs are HOST doubles / ints.
+ *   eioku_scene_scores_from_sad : libavfilter get_scene_score over a SAD series (mafd, clip(float32(min(mafd,
+ *                                 |mafd - prev|) / 100))); count = pixels per plane.
+ *   eioku_scene_scores_luma     : K1 + the above on luma planes (host or device); synchronises the stream.
+ *   eioku_scene_content_scores  : ContentDetector score (dh + ds + dl + 0) / 3 from K2's sums [n][3].
+ *   eioku_scene_content_cuts    : PySceneDetect cut filter; mode 0 = 0.6.0-0.6.3 / SUPPRESS, 1 = 0.6.4+ MERGE.
+ *   eioku_scene_content         : K2 + score + cuts on BGR frames (host or device); synchronises the stream. */
+int eioku_scene_scores_from_sad(const uint64_t* sad, int n, double count, int bitdepth, double prev_mafd, int first_has_prev,
+                                double* mafd_out, double* score_out);
+int eioku_scene_scores_luma(const uint8_t* y_frames, int n, int h, int w, size_t row_stride, size_t frame_stride,
+                            const uint8_t* prev, double prev_mafd, double* mafd_out, double* score_out, int mem,
+                            void* stream);
+int eioku_scene_content_scores(const uint64_t* sums, int n, double num_pixels, int first_has_prev, double* score_out);
+int eioku_scene_content_cuts(const double* scores, int n, double threshold, int min_scene_len, int mode, int32_t* cuts_out,
+                             int cap, int* n_cuts);
+int eioku_scene_content(const uint8_t* bgr_frames, int n, int h, int w, const uint8_t* prev, double threshold,
+                        int min_scene_len, int mode, int32_t* cuts_out, int cap, int* n_cuts, double* score_out, int mem,
+                        void* stream);
+
 /* Debug / parity helper: the HSV image itself (same layout as the input). */
 int eioku_bgr2hsv(const uint8_t* bgr, size_t n_pixels, uint8_t* hsv_out, int mem, void* stream);
 
@@ -125,6 +147,7 @@ int eioku_bgr2hsv(const uint8_t* bgr, size_t n_pixels, uint8_t* hsv_out, int mem
  *               channels starting at `in_coff` (a concat/chunk slice).  cin, strides, offsets % 8 == 0.
  *   weight    : HOST fp32 [cout][cin][k][k] (torch layout), bias HOST fp32 [cout] or NULL; rounded
  *               to fp16 like tensor.half().
+ *   act_silu  : 0 none, 1 SiLU, 2 ReLU, 3 ReLU AFTER the residual sum (relu(fp16(conv + bias) + res): ResNet blocks).
  *   residual  : optional fp16 slice added after activation: out = fp16(fp16(act(..)) + res).
  *   out_nhwc  : fp16 slice (cstride/coff % 4 == 0), or out_f32 != NULL: dense fp32 [n,ho,wo,cout].
  * Synchronous (packs weights per call): a test / building-block entry, not the fast path.
@@ -342,6 +365,36 @@ int eioku_ivfpq_search_lists(const float* q_dev, int nq, int d, int m, const lon
                              const float* query_tables_dev, const void* pqh_dev, const float* hx_dev,
                              const float* pmax2_dev, int k, int cand_cap, void* workspace_dev, long long workspace_bytes,
                              float* D_dev, long long* I_dev, int* stats_out_dev, void* stream);
+
+/* ---- place classification: Places365 ResNet18 (csrc/resnet.hip) --------------------------------------------------
+ * Replaces the per-frame arithmetic of ModelManager.classify_places
+ * (/root/reference/ml-service/src/services/model_manager.py:560-713): `transforms.Resize((224, 224))` on the PIL image
+ * (Pillow's antialiased bilinear resample, bit-exact: model_manager.py:630-640), ToTensor + Normalize,
+ * `models.resnet18` with a 365-way fc (:609-624), softmax + descending sort + top_k (:672-687).
+ * Weights are set per convolution with BatchNorm folded in (eioku_resnet18_conv_info names them as torchvision's
+ * state dict does: "conv1", "layer1.0.conv1", ..., "layer2.0.downsample.0"); fp16 storage, fp32 accumulation.
+ * The resize tables are Pillow's precompute_coeffs output for (w -> 224) and (h -> 224), computed by the host
+ * (eioku_amd/places.py): bounds [224][2] = {first input index, taps}, k [224][ksize] int32 taps x 2^22. */
+typedef struct eioku_resnet eioku_resnet_t;
+int eioku_resnet18_create(int num_classes, eioku_resnet_t** out);
+void eioku_resnet18_destroy(eioku_resnet_t* r);
+int eioku_resnet18_num_convs(const eioku_resnet_t* r);
+int eioku_resnet18_conv_info(const eioku_resnet_t* r, int idx, char* name, size_t name_cap, int* cout, int* cin, int* ksize,
+                             int* stride);
+int eioku_resnet18_set_conv(eioku_resnet_t* r, int idx, const float* weight_oihw, const float* bias);
+int eioku_resnet18_set_fc(eioku_resnet_t* r, const float* weight, const float* bias);
+/* resize + normalise only: out_f16 [n][224][224][4] fp16 (R, G, B, 0) and / or out_rgb_u8 [n][224][224][3], DEVICE */
+int eioku_places_preprocess(eioku_resnet_t* r, const uint8_t* bgr, int n, int h, int w, const int32_t* xbounds,
+                            const int32_t* xk, int kx, const int32_t* ybounds, const int32_t* yk, int ky, void* out_f16,
+                            uint8_t* out_rgb_u8, int mem, void* stream);
+/* the raw network: in [n][224][224][4] fp16 -> logits [n][num_classes] fp32; device pointers, asynchronous */
+int eioku_resnet18_forward(eioku_resnet_t* r, const void* in_nhwc4_f16, int n, float* logits_out, void* stream);
+/* n BGR frames (host or device) -> per frame the top_k (probability, class) of softmax(logits) in descending order
+ * (ties: lower class); outputs on the side `mem` names (host outputs synchronise); logits_out optional */
+int eioku_resnet18_classify(eioku_resnet_t* r, const uint8_t* bgr, int n, int h, int w, const int32_t* xbounds,
+                            const int32_t* xk, int kx, const int32_t* ybounds, const int32_t* yk, int ky, int top_k,
+                            float* prob_out, int32_t* class_out, float* logits_out, int mem, void* stream);
+int eioku_resnet18_last_flops(const eioku_resnet_t* r, double* flops);
 
 #ifdef __cplusplus
 }

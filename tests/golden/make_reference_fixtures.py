@@ -22,6 +22,12 @@ the hot path that exists as code under /root/reference:
                          projection tables of backend/alembic (scene_ranges / object_labels / face_clusters): the
                          envelopes fed in and the table rows that result - what the batched writer must reproduce.
 
+  ref_places_loop.json   ModelManager.classify_places (model_manager.py:560-713) with stub ``cv2`` /
+                         ``torchvision`` modules (the real ``torch`` and ``PIL``): frame sampling, timestamps,
+                         label-file parsing (and the generic fallback), softmax -> descending sort -> top_k,
+                         ``float(probs[j])`` widening.  The stub model returns scripted logits
+                         (``places_logits(seed, frame_index)``); the network's arithmetic is NOT pinned by it.
+
 Only inputs and outputs are stored (JSON data); no reference source text is copied.
 The stubs stand in for cv2 / ultralytics / ffmpeg *calls*, i.e. the inputs of the orchestration
 under test; the arithmetic inside those libraries is NOT pinned by these fixtures.
@@ -151,6 +157,89 @@ def capture_detect_loop(ModelManager):
         cases.append({"kind": kind, "fps": fps, "total_frames": total, "config": config, "seed": seed,
                       "names": {str(k): v for k, v in names.items()},
                       "detector_calls": calls, "result": result})
+    return cases
+
+
+def places_logits(seed: int, frame_idx: int) -> np.ndarray:
+    """Scripted network output of one frame (float32 [365]); tests regenerate it from (seed, frame_index)."""
+    rng = np.random.default_rng(seed * 1_000_003 + frame_idx)
+    return (3.0 * rng.standard_normal(365)).astype(np.float32)
+
+
+def install_places_stubs(fps: float, total: int, seed: int):
+    install_stubs(fps, total, seed, {})
+    cv2 = sys.modules["cv2"]
+    cv2.COLOR_BGR2RGB = 4
+    cv2.cvtColor = lambda frame, code: np.ascontiguousarray(frame[..., ::-1])
+    tv = types.ModuleType("torchvision")
+    models = types.ModuleType("torchvision.models")
+    transforms = types.ModuleType("torchvision.transforms")
+    calls = []
+
+    class _Model:
+        def __init__(self):
+            self.fc = types.SimpleNamespace(in_features=512)
+
+        def load_state_dict(self, sd):
+            calls.append({"load_state_dict": sorted(sd)[:3]})
+
+        def to(self, device):
+            return self
+
+        def eval(self):
+            return self
+
+        def __call__(self, x):  # x: (1, 3, 4, 4) uint8-valued float tensor carrying the frame index in pixel (0, 0)
+            px = x[0, :, 0, 0]
+            idx = int(px[2]) | (int(px[1]) << 8) | (int(px[0]) << 16)  # RGB order after the BGR2RGB stub
+            calls.append({"frame_index": idx})
+            return torch.from_numpy(places_logits(seed, idx))[None]
+
+    models.resnet18 = lambda pretrained=False: _Model()
+
+    class Compose:
+        def __init__(self, ts):
+            pass
+
+        def __call__(self, img):  # PIL image -> CHW float tensor of its bytes (the real transform is the device's job)
+            return torch.from_numpy(np.asarray(img)).permute(2, 0, 1).to(torch.float32)
+
+    transforms.Compose = Compose
+    transforms.Resize = lambda size: ("resize", size)
+    transforms.ToTensor = lambda: "totensor"
+    transforms.Normalize = lambda mean, std: ("normalize", mean, std)
+    tv.models, tv.transforms = models, transforms
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = models
+    sys.modules["torchvision.transforms"] = transforms
+    return calls
+
+
+def capture_places_loop(ModelManager):
+    cases = []
+    specs = [
+        (30.0, 95, {}, True),                                     # defaults: every 30th frame, top_k 5, label file present
+        (29.97, 200, {"frame_interval": 3.0, "top_k": 3}, True),
+        # (a case without <cache>/places365/categories_places365.txt would not pin the generic place_<i> fallback: the
+        # reference then finds the list it ships beside ml-service/src - model_manager.py:583-590 - so every case
+        # provides the cache-dir file, the first location looked at)
+        (23.976, 61, {"frame_interval": 0.5, "top_k": 1}, True),
+        (0.0, 40, {"top_k": 400}, True),                          # fps 0 -> `or 30`; top_k beyond 365 classes
+        (25.0, 0, {}, True),                                      # empty video
+    ]
+    label_lines = [f"/{chr(97 + i % 26)}/label_{i} {i}" for i in range(365)]
+    for seed, (fps, total, config, with_labels) in enumerate(specs, start=11):
+        calls = install_places_stubs(fps, total, seed)
+        with tempfile.TemporaryDirectory() as td:
+            if with_labels:
+                d = Path(td) / "places365"
+                d.mkdir(parents=True)
+                (d / "categories_places365.txt").write_text("\n".join(label_lines) + "\n")
+            mm = ModelManager(cache_dir=td)
+            result = asyncio.run(mm.classify_places("/videos/fake.mp4", dict(config)))
+        cases.append({"fps": fps, "total_frames": total, "config": config, "seed": seed, "label_file": with_labels,
+                      "label_lines": label_lines if with_labels else None,
+                      "model_calls": [c["frame_index"] for c in calls if "frame_index" in c], "result": result})
     return cases
 
 
@@ -288,6 +377,7 @@ def main():
 
     (HERE / "ref_detect_loop.json").write_text(json.dumps(capture_detect_loop(ModelManager), indent=1))
     (HERE / "ref_scenes.json").write_text(json.dumps(capture_scenes(ModelManager), indent=1))
+    (HERE / "ref_places_loop.json").write_text(json.dumps(capture_places_loop(ModelManager)) + "\n")
     (HERE / "ref_artifact_spans.json").write_text(json.dumps(capture_artifact_rules(), indent=1))
     (HERE / "ref_projection_rows.json").write_text(json.dumps(capture_projection_rows(), indent=1) + "\n")
     print("wrote fixtures to", HERE)
@@ -300,7 +390,19 @@ def main_projection_only():
     print("wrote ref_projection_rows.json:", {k: len(v) for k, v in out["tables"].items()})
 
 
+def main_places_only():
+    sys.path.insert(0, str(REF))
+    from src.services.model_manager import ModelManager
+
+    out = capture_places_loop(ModelManager)
+    (HERE / "ref_places_loop.json").write_text(json.dumps(out) + "\n")
+    print("wrote ref_places_loop.json:", [len(c["result"]["classifications"]) for c in out])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "places":
+        main_places_only()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "projection":
         main_projection_only()
         sys.exit(0)

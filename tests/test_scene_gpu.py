@@ -151,3 +151,33 @@ def test_full_size_1080p_properties(gpu):
     sad = scene.luma_sad(y)
     assert np.array_equal(sad[38], oscene.luma_sad(two[..., 1])[1])
     assert np.array_equal(np.concatenate([scene.luma_sad(y[:33]), scene.luma_sad(y[33:], prev=y[32])]), sad)
+
+
+def test_scores_and_cuts_behind_the_c_abi(gpu):
+    """libavfilter's score (double -> float32 clip) and the PySceneDetect cut filter live behind the C
+    ABI (eioku_scene_scores_luma / eioku_scene_content): host and device inputs, with and without a carried previous
+    frame, against the oracle - bit for bit (the scores are float64 images of exact integer sums)."""
+    import torch
+
+    n, h, w = 40, 72, 96
+    host = prng.synth_frames_bgr(1234, n, h, w, first_frame=185)
+    y = np.ascontiguousarray(host[..., 1])
+    sad = oscene.luma_sad(y)
+    mafd_o, score_o = oscene.ffmpeg_scene_scores(sad, h * w)
+    for src in (y, torch.from_numpy(y).to(gpu)):
+        mafd, score = scene.scene_scores_luma(src)
+        assert np.array_equal(mafd, mafd_o) and np.array_equal(score, score_o)
+    # streaming: the second half scored with the first half's last plane / mafd carried over
+    k = 17
+    m1, s1 = scene.scene_scores_luma(torch.from_numpy(y[:k]).to(gpu))
+    m2, s2 = scene.scene_scores_luma(torch.from_numpy(y[k:]).to(gpu), prev=torch.from_numpy(y[k - 1]).to(gpu), prev_mafd=float(m1[-1]))
+    assert np.array_equal(np.concatenate([m1, m2]), mafd_o) and np.array_equal(np.concatenate([s1, s2]), score_o)
+    sums = oscene.content_sums(host)
+    sc_o = oscene.content_scores(sums, h * w)
+    for mode in ("legacy", "merge"):
+        for msl in (0, 3, 15):
+            want = oscene.content_cuts(sc_o, 27.0, msl, mode)
+            for src in (host, torch.from_numpy(host).to(gpu)):
+                cuts, sc = scene.content_detect(src, threshold=27.0, min_scene_len=msl, mode=mode)
+                assert cuts == want and np.array_equal(sc, sc_o), (mode, msl)
+    assert len(oscene.content_cuts(sc_o, 27.0, 3)) >= 1  # the synthetic video does hold cuts
