@@ -53,6 +53,7 @@ SIGNATURES = {
                                            C.POINTER(C.c_int)]),
     "eioku_scene_content": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p,
                                       C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p]),
+    "eioku_yuv420_to_bgr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "eioku_bgr2hsv": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "eioku_conv2d_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -48,6 +48,14 @@ class FrameSource:
         """``(count,h,w)`` uint8 luma of frames [start, start+count) for the scene stage."""
         raise NotImplementedError
 
+    # Decoder planes (SURVEY.md 8f rank 1): a source that can hand over the decoded 4:2:0 frame itself - 1.5 bytes per
+    # pixel - names its layout here ("i420" / "nv12") and implements read_yuv(); the single-pass ingest then uploads the
+    # planes and converts to BGR on the device (eioku_yuv420_to_bgr).  None: BGR only.
+    yuv_layout: str | None = None
+
+    def read_yuv(self):  # -> (ok, planar uint8 (3h/2, w) frame in OpenCV's Mat layout)
+        raise NotImplementedError
+
 
 def _fps_to_time_base(fps: float) -> tuple[int, int]:
     fr = Fraction(fps).limit_denominator(1001)
@@ -125,6 +133,18 @@ class Y4mSource(FrameSource):
         self.duration_s = self.total_frames / self.fps
         self.pos = 0
         self._mm = np.memmap(self.path, dtype=np.uint8, mode="r")
+        # 4:2:0 clips with even sizes hand their planes to the single-pass ingest as they are (I420)
+        if cs.startswith("420") and w % 4 == 0 and h % 2 == 0:
+            self.yuv_layout = "i420"
+
+    def read_yuv(self):
+        if self.yuv_layout is None:
+            raise RuntimeError(f"{self.path}: only 4:2:0 y4m clips (w % 4 == 0, h % 2 == 0) carry planes the device converts")
+        if self.pos >= self.total_frames:
+            return False, None
+        off = self.header_len + self.pos * (6 + self.frame_bytes) + 6
+        self.pos += 1
+        return True, np.asarray(self._mm[off:off + self.frame_bytes]).reshape(self.h * 3 // 2, self.w)
 
     def luma_planes(self, start, count):
         out = np.empty((count, self.h, self.w), dtype=np.uint8)
@@ -191,6 +211,41 @@ class Cv2FrameSource(FrameSource):
         if self._ycap is not None:
             self._ycap.release()
             self._ycap = None
+
+    # ---- decoder planes for the single-pass ingest ---------------------------------------------------------
+    def try_yuv(self) -> bool:
+        """Re-open the capture with ``CAP_PROP_CONVERT_RGB = 0``; when the backend answers with planar 4:2:0 frames
+        ``(3h/2, w)`` (OpenCV's FFmpeg backend does for yuv420p streams) those are what ``read_yuv`` returns from now on
+        and ``yuv_layout`` names their layout (``EIOKU_CV2_RAW_LAYOUT``, default ``i420``: a shape cannot tell I420 from
+        NV12).  False - and nothing changed - when the backend ignores the property or hands back something else."""
+        import os
+
+        cv2 = self._cv2
+        cap = cv2.VideoCapture(self.path)
+        cap.set(cv2.CAP_PROP_CONVERT_RGB, 0)
+        hh = int(cap.get(cv2.CAP_PROP_FRAME_HEIGHT))
+        ok, f = cap.read()
+        cap.release()
+        f = np.asarray(f) if ok else None
+        if f is not None and f.ndim == 3 and f.shape[2] == 1:
+            f = f.reshape(f.shape[0], f.shape[1])
+        if f is None or f.ndim != 2 or hh <= 0 or f.shape[0] != hh * 3 // 2 or hh % 2 or f.shape[1] % 4:
+            return False
+        self.cap.release()
+        self.cap = cv2.VideoCapture(self.path)
+        self.cap.set(cv2.CAP_PROP_CONVERT_RGB, 0)
+        self.yuv_layout = os.environ.get("EIOKU_CV2_RAW_LAYOUT", "i420")
+        self._yuv_h = hh
+        return True
+
+    def read_yuv(self):
+        if self.yuv_layout is None:
+            raise RuntimeError("try_yuv() first: this capture hands back BGR")
+        ok, f = self.cap.read()
+        if not ok:
+            return False, None
+        f = np.asarray(f)
+        return True, f.reshape(f.shape[0], f.shape[1])
 
     def _luma_of(self, frame) -> np.ndarray:
         f = np.asarray(frame)

@@ -324,7 +324,7 @@ class ModelManager:
         from . import scene
         from .detect import PipelinedDetector
 
-        unknown = set(configs) - {"scene_detection", "object_detection", "face_detection"}
+        unknown = set(configs) - {"scene_detection", "object_detection", "face_detection", "decode"}
         if unknown:
             raise NotImplementedError(f"analyze_video covers the hot-path task types only, got {sorted(unknown)}")
         logger.info(f"Single-pass analysis ({', '.join(sorted(configs))}): {video_path} (device: {self._get_device()})")
@@ -333,6 +333,14 @@ class ModelManager:
         total_frames = int(src.total_frames)
         dev = torch.device("cuda", torch.cuda.current_device())
         chunk_n = max(1, self._batch_size)
+        # Decoder planes when the source can hand them over (a .y4m clip, a cv2 capture that honours CONVERT_RGB = 0):
+        # 1.5 bytes per pixel cross PCIe instead of 3, the scene score is taken on the decoder's own Y plane (what ffmpeg's
+        # select filter scores: bit-exact with the separate detect_scenes), and the BGR frames the detectors / the
+        # ContentDetector read are produced on the device with OpenCV's integer BT.601 (eioku_yuv420_to_bgr) - the
+        # conversion cap.read() would have run on the CPU
+        if getattr(src, "yuv_layout", None) is None and hasattr(src, "try_yuv") and configs.get("decode", {}).get("planes", True):
+            src.try_yuv()
+        yuv = getattr(src, "yuv_layout", None)
         lanes = {}  # task -> detection lane state
         for task, face, dflt_model, dflt_conf, dflt_sec in (("object_detection", False, "yolov8n.pt", 0.5, 1),
                                                             ("face_detection", True, "yolov8n-face.pt", 0.7, 3)):
@@ -385,7 +393,7 @@ class ModelManager:
             while not done:
                 host = []
                 while len(host) < chunk_n:
-                    ret, frame = src.read()
+                    ret, frame = src.read_yuv() if yuv else src.read()
                     if not ret:
                         done = True
                         break
@@ -394,21 +402,34 @@ class ModelManager:
                     break
                 n = len(host)
                 h, w = host[0].shape[:2]
+                fshape = (h, w) if yuv else (h, w, 3)
+                if yuv:
+                    h = h * 2 // 3
                 npx = h * w
-                if pinned[slot] is None or tuple(pinned[slot].shape[1:]) != (h, w, 3):
-                    pinned = [torch.empty((chunk_n, h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+                if pinned[slot] is None or tuple(pinned[slot].shape[1:]) != fshape:
+                    pinned = [torch.empty((chunk_n, *fshape), dtype=torch.uint8).pin_memory() for _ in range(2)]
                     copied = [None, None]
                 if copied[slot] is not None:
                     copied[slot].synchronize()  # the upload that last used this pinned buffer has finished
                 buf = pinned[slot][:n]
-                for i, f in enumerate(host):
-                    buf[i] = torch.from_numpy(np.ascontiguousarray(f))
+                view = buf.numpy()  # the pinned buffer as an ndarray: frames are copied in without wrapping (possibly
+                for i, f in enumerate(host):  # read-only, memory-mapped) source arrays as tensors
+                    view[i] = f
                 chunk = buf.to(dev, non_blocking=True)  # the one trip over PCIe
                 ev = torch.cuda.Event()
                 ev.record()
                 copied[slot] = ev
                 slot ^= 1
-                if want_scenes:
+                planes = None
+                if yuv:
+                    planes = chunk
+                    chunk = scene.yuv420_to_bgr(planes, h, w, yuv) if (lanes or (want_scenes and content)) else None
+                if want_scenes and planes is not None and not content:
+                    # K1 straight on the Y planes of the uploaded frames: rows 0 .. h-1 of every (3h/2, w) frame
+                    sums.append(scene.luma_sad(planes, prev_dev, shape=(n, h, w), row_stride=w, frame_stride=h * 3 // 2 * w,
+                                               keep_on_device=True))
+                    prev_dev = planes[n - 1]
+                elif want_scenes:
                     if content:
                         sums.append(scene.hsv_sums(chunk, prev_dev, keep_on_device=True))
                     elif npx % 4 == 0:

@@ -118,6 +118,29 @@ def content_detect(bgr_frames, prev=None, threshold: float = 27.0, min_scene_len
     return [int(t) for t in cuts[:found.value]], scores
 
 
+def yuv420_to_bgr(yuv, h: int, w: int, layout: str = "i420"):
+    """Decoder planes -> BGR frames with OpenCV's integer BT.601 (``eioku_yuv420_to_bgr``): ``yuv`` uint8
+    ``(n, 3h/2, w)`` in OpenCV's planar Mat layout (numpy: staged; CUDA tensor: zero copy) -> ``(n,h,w,3)`` on the same
+    side.  ``layout``: ``"i420"`` (Y | U | V) or ``"nv12"`` (Y | interleaved UV)."""
+    lib = _lib.load()
+    _lib.init()
+    if layout not in ("i420", "nv12"):
+        raise ValueError(f"unknown layout {layout!r}")
+    n = int(yuv.shape[0])
+    if tuple(int(v) for v in yuv.shape[1:]) != (h * 3 // 2, w):
+        raise ValueError(f"expected (n, {h * 3 // 2}, {w}) planar frames, got {tuple(yuv.shape)}")
+    if on_device(yuv):
+        import torch
+
+        out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=yuv.device)
+    else:
+        yuv = np.ascontiguousarray(yuv, dtype=np.uint8)
+        out = np.empty((n, h, w, 3), np.uint8)
+    _lib.check(lib.eioku_yuv420_to_bgr(ptr(yuv), n, h, w, 1 if layout == "nv12" else 0, ptr(out), same_side(yuv), current_stream(yuv)),
+               "eioku_yuv420_to_bgr")
+    return out
+
+
 def bgr2hsv(bgr):
     """OpenCV-compatible 8-bit BGR->HSV image (parity/debug helper)."""
     lib = _lib.load()

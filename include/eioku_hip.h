@@ -135,6 +135,14 @@ int eioku_scene_content(const uint8_t* bgr_frames, int n, int h, int w, const ui
                         int min_scene_len, int mode, int32_t* cuts_out, int cap, int* n_cuts, double* score_out, int mem,
                         void* stream);
 
+/* ---- decoder planes in, BGR on the device (csrc/yuv.hip) ----
+ * OpenCV's 8-bit COLOR_YUV2BGR_I420 / _NV12 (BT.601 studio range, 20-bit fixed point): the conversion cap.read() runs on
+ * the CPU inside the reference's frame loops (model_manager.py:237-297,331-398).  yuv: n frames of (3h/2) x w bytes in
+ * OpenCV's planar Mat layout (layout 0 = I420: Y | U | V, 1 = NV12: Y | interleaved UV); bgr_out [n][h][w][3]; both on
+ * the side `mem` names.  h even, w a multiple of 4.  The Y plane itself (rows 0 .. h-1 of every frame) is what
+ * eioku_scene_sad_luma scores with frame_stride = 3 h w / 2. */
+int eioku_yuv420_to_bgr(const uint8_t* yuv, int n, int h, int w, int layout, uint8_t* bgr_out, int mem, void* stream);
+
 /* Debug / parity helper: the HSV image itself (same layout as the input). */
 int eioku_bgr2hsv(const uint8_t* bgr, size_t n_pixels, uint8_t* hsv_out, int mem, void* stream);
 

@@ -66,6 +66,8 @@ def test_single_pass_on_a_cv2_capture_reads_each_frame_once(gpu, monkeypatch, tm
     got = asyncio.run(mm.analyze_video("/videos/clip.mp4", CONFIGS))
     assert got == want
     mine = cv2.opened[opened_before:]
-    assert len(mine) == 1 and mine[0].pos == 230 and mine[0].released  # ONE capture, every frame read exactly once
+    # ONE capture decodes the file, every frame read exactly once (+ the one-frame probe that asked the backend for the
+    # decoder's planes and was answered with BGR: this stub ignores CAP_PROP_CONVERT_RGB)
+    assert len(mine) == 2 and mine[0].pos == 230 and mine[0].released and mine[1].pos == 1 and mine[1].released
     # the three separate calls opened 4 captures (objects, faces, scenes + its luma capture) and decoded 3 x 230 frames
     assert opened_before >= 3
