@@ -12,7 +12,8 @@ import threading
 from pathlib import Path
 
 _PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = _PKG_DIR / "libeioku_hip.so"
+# EIOKU_HIP_LIB: another build of the same ABI (tests load libeioku_hip_bc.so, the bounds-check build, in a child process)
+LIB_PATH = Path(os.environ["EIOKU_HIP_LIB"]) if os.environ.get("EIOKU_HIP_LIB") else _PKG_DIR / "libeioku_hip.so"
 
 MEM_HOST = 0
 MEM_DEVICE = 1
@@ -59,6 +60,7 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p]),
+    "eioku_debug_bounds": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int]),
     "eioku_yolo_create": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "eioku_yolo_destroy": (None, [C.c_void_p]),
     "eioku_yolo_num_convs": (C.c_int, [C.c_void_p]),

@@ -29,6 +29,56 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 
 constexpr int kTH = 8, kTW = 16;
 
+// ---- bounds-check build (`make bc` -> libeioku_hip_bc.so, -DEIOKU_BOUNDS_CHECK) -------------------
+// Round 2's GPU memory fault was an over-read past the end of a tensor that only faulted when the allocation ended on a
+// page boundary.  In the bounds-check build every global access of an activation / residual / image / output tensor
+// in this file goes through LDG / STG: the address range is compared with the tensor's extent (set by the host
+// wrappers from the slice geometry), a violation bumps a device counter and records the source line - no trap, the
+// access is skipped - and tests/test_bounds_gpu.py asserts the counter stayed 0 over the conv test cases and whole
+// forwards of three model sizes and four source geometries.  The regular build compiles LDG / STG to plain accesses.
+struct BcExt {
+  const char* lo = nullptr;
+  const char* hi = nullptr;
+};
+#ifdef EIOKU_BOUNDS_CHECK
+__device__ int g_bc_flag[4];  // [0] violations, [1] largest source line of a violation
+// bytes the access really touches: a 3-element vector is a 12-byte load (global_load_dwordx3) in a 16-byte type
+template <typename V>
+struct bc_bytes {
+  static constexpr size_t value = sizeof(V);
+};
+template <>
+struct bc_bytes<unsigned __attribute__((ext_vector_type(3)))> {
+  static constexpr size_t value = 12;
+};
+template <typename V>
+__device__ __forceinline__ V bc_ld(const void* p, BcExt e, int line) {
+  const char* c = reinterpret_cast<const char*>(p);
+  if (c < e.lo || c + bc_bytes<V>::value > e.hi) {
+    atomicAdd(&g_bc_flag[0], 1);
+    atomicMax(&g_bc_flag[1], line);
+    V z{};
+    return z;
+  }
+  return *reinterpret_cast<const V*>(p);
+}
+template <typename V>
+__device__ __forceinline__ void bc_st(void* p, V v, BcExt e, int line) {
+  const char* c = reinterpret_cast<const char*>(p);
+  if (c < e.lo || c + sizeof(V) > e.hi) {
+    atomicAdd(&g_bc_flag[0], 1);
+    atomicMax(&g_bc_flag[1], line);
+    return;
+  }
+  *reinterpret_cast<V*>(p) = v;
+}
+#define LDG(V, p, ext) bc_ld<V>((p), (ext), __LINE__)
+#define STG(V, p, v, ext) bc_st<V>((p), (v), (ext), __LINE__)
+#else
+#define LDG(V, p, ext) (*reinterpret_cast<const V*>(p))
+#define STG(V, p, v, ext) (*reinterpret_cast<V*>(p) = (v))
+#endif
+
 struct ConvArgs {
   const __half* in;
   const uint4* wgt;
@@ -52,6 +102,8 @@ struct ConvArgs {
   // the half-resolution tensor in2 at (y/2, x/2) instead of from `in` -- the upsampled tensor is never written
   const __half* in2;
   int in2_cs, c_split;
+  // tensor extents, read by the bounds-check build only
+  BcExt x_in, x_in2, x_res, x_out, x_img, x_cls;
 };
 
 // x / d for 0 <= x < 2^24 (exact int->float) with a precomputed 1.0f/d: one multiply and a +-1 fix-up instead
@@ -118,34 +170,34 @@ __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc
   if (a.out_f32) {
     float* o = a.out_f32 + opix * a.Cout + c0;
     if (full && (a.Cout & 3) == 0) {
-      *reinterpret_cast<float4v*>(o) = v;
+      STG(float4v, o, v, a.x_out);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (c0 + j < a.Cout) o[j] = v[j];
+        if (c0 + j < a.Cout) STG(float, o + j, v[j], a.x_out);
     }
     return;
   }
   f16x4 h = __builtin_convertvector(v, f16x4);  // RNE
   if (full) {
     if (a.res) {
-      const u32x2 r = have_rpre ? rpre : *reinterpret_cast<const u32x2*>(a.res + opix * a.res_cs + c0);
+      const u32x2 r = have_rpre ? rpre : LDG(u32x2, a.res + opix * a.res_cs + c0, a.x_res);
       float4v sum = __builtin_convertvector(h, float4v) + __builtin_convertvector(__builtin_bit_cast(f16x4, r), float4v);
       if (a.act == kActResReLU) sum = __builtin_elementwise_max(sum, float4v{0.f, 0.f, 0.f, 0.f});
       h = __builtin_convertvector(sum, f16x4);
     }
-    *reinterpret_cast<u32x2*>(a.out + opix * a.out_cs + c0) = __builtin_bit_cast(u32x2, h);
+    STG(u32x2, a.out + opix * a.out_cs + c0, __builtin_bit_cast(u32x2, h), a.x_out);
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (c0 + j < a.Cout) {
         _Float16 o = h[j];
         if (a.res) {
-          float sj = (float)o + __half2float(a.res[opix * a.res_cs + c0 + j]);
+          float sj = (float)o + (float)LDG(_Float16, a.res + opix * a.res_cs + c0 + j, a.x_res);
           if (a.act == kActResReLU) sj = fmaxf(sj, 0.f);
           o = (_Float16)sj;
         }
-        reinterpret_cast<_Float16*>(a.out)[opix * a.out_cs + c0 + j] = o;
+        STG(_Float16, reinterpret_cast<_Float16*>(a.out) + opix * a.out_cs + c0 + j, o, a.x_out);
       }
   }
 }
@@ -197,7 +249,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1(ConvArgs a, long long npix
         int c = (kb * KB + j) * 32;
         if (c + u * 8 >= a.Cin) c = 0;  // past Cin: any in-range address; zeroed below / never multiplied
         const __half* base = (UP && c < a.c_split) ? src2 : src;
-        b[j][m] = *reinterpret_cast<const u32x4*>(base + c);
+        b[j][m] = LDG(u32x4, base + c, (UP && c < a.c_split) ? a.x_in2 : a.x_in);
       }
     }
   };
@@ -299,7 +351,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1(ConvArgs a, long long npix
           }
         }
         const long long p = g * 32 + m * 16 + r;
-        if (u == 0 && p < npix) a.clsmax[p] = ((unsigned long long)(unsigned)bj << 32) | __float_as_uint(best);
+        if (u == 0 && p < npix) STG(unsigned long long, a.clsmax + p, ((unsigned long long)(unsigned)bj << 32) | __float_as_uint(best), a.x_cls);
       }
     } else {
 #pragma unroll
@@ -418,7 +470,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     const bool past = cin_tail && cc * 32 + (tid & 3) * 8 >= a.Cin;  // units past Cin: see k_conv3x3_flat
     const __half* src = a.in + (past ? 0 : cc * 32);
 #pragma unroll
-    for (int j = 0; j < R; ++j) sreg[j] = *reinterpret_cast<const u32x4*>(src + (past ? 0 : s_g[j]));
+    for (int j = 0; j < R; ++j) sreg[j] = LDG(u32x4, src + (past ? 0 : s_g[j]), a.x_in);
 #pragma unroll
     for (int j = 0; j < WREG; ++j)
       if (WT_U % 256 == 0 || tid + j * 256 < WT_U) wreg[j] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)cc * WT_U + j * 256);
@@ -534,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_flat(ConvArgs a, int npix, i
     const bool past = cin_tail && cc * 32 + (tid & 3) * 8 >= a.Cin;
     const __half* src = a.in + (past ? 0 : cc * 32);
 #pragma unroll
-    for (int j = 0; j < NS; ++j) sreg[j] = *reinterpret_cast<const u32x4*>(src + (past ? 0 : s_g[j]));
+    for (int j = 0; j < NS; ++j) sreg[j] = LDG(u32x4, src + (past ? 0 : s_g[j]), a.x_in);
 #pragma unroll
     for (int j = 0; j < WREG; ++j)
       if (WT_U % 256 == 0 || tid + j * 256 < WT_U) wreg[j] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)cc * WT_U + j * 256);
@@ -678,7 +730,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv3x3_persist(ConvArgs a, int to
       const int ih = ih0 + s_py[j], iw = iw0 + s_px[j];
       const bool ok = ((s_live >> j) & 1) && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
       s_ok |= (ok ? 1u : 0u) << j;
-      stage[j] = *reinterpret_cast<const u32x4*>(a.in + (ok ? base + s_rel[j] : 0));
+      stage[j] = LDG(u32x4, a.in + (ok ? base + s_rel[j] : 0), a.x_in);
     }
   };
 
@@ -758,7 +810,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv3x3_persist(ConvArgs a, int to
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           const int c0 = co_tile * 16 * NF + f * 16 + (lane >> 4) * 4;
-          resv[m][f] = *reinterpret_cast<const u32x2*>(a.res + opix * a.res_cs + (c0 + 3 < a.Cout ? c0 : 0));
+          resv[m][f] = LDG(u32x2, a.res + opix * a.res_cs + (c0 + 3 < a.Cout ? c0 : 0), a.x_res);
         }
       }
     }
@@ -866,6 +918,7 @@ struct ChainCat {
   int out_cs, act;
   const __half* cat;   // channel 0 of the concat buffer
   int cat_cs;
+  BcExt x_cat, x_out;  // bounds-check build
 };
 
 template <int NF, bool DB, int CAT = 0, int NF2 = 2>
@@ -921,7 +974,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, 
       const int ih = ih0 + s_py[j], iw = iw0 + s_px[j];
       const bool ok = ((s_live >> j) & 1) && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
       s_ok |= (ok ? 1u : 0u) << j;
-      stage[j] = *reinterpret_cast<const u32x4*>(a.in + (ok ? base + s_rel[j] : 0));
+      stage[j] = LDG(u32x4, a.in + (ok ? base + s_rel[j] : 0), a.x_in);
     }
   };
 
@@ -1023,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, 
         if (owc >= a.Wo) owc = a.Wo - 1;
         const __half* src = cc.cat + (((size_t)tn * a.Ho + oh) * a.Wo + owc) * cc.cat_cs + (lane >> 4) * 8;
 #pragma unroll
-        for (int c = 0; c < CAT; ++c) gB[c][m] = *reinterpret_cast<const u32x4*>(src + c * 32);
+        for (int c = 0; c < CAT; ++c) gB[c][m] = LDG(u32x4, src + c * 32, cc.x_cat);
       }
     }
     const int next = tile + gridDim.x;
@@ -1089,7 +1142,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, 
           const int unit = f * 2 + (lane >> 5), half = (lane >> 4) & 1;
           *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(xb + pos * 4 + (unit ^ ((pos >> 1) & 3))) + half * 8) = __builtin_bit_cast(u32x2, h);
         } else {
-          *reinterpret_cast<u32x2*>(a.post_out + opix * a.post_out_cs + f * 16 + (lane >> 4) * 4) = __builtin_bit_cast(u32x2, h);
+          STG(u32x2, a.post_out + opix * a.post_out_cs + f * 16 + (lane >> 4) * 4, __builtin_bit_cast(u32x2, h), a.x_out);
         }
       }
     }
@@ -1132,7 +1185,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, 
           float4v v = acc2[m][f] + float4v{bias2[f].x, bias2[f].y, bias2[f].z, bias2[f].w};
           if (cc.act == kActSiLU) v = silu4(v);
           const f16x4 h = __builtin_convertvector(v, f16x4);
-          *reinterpret_cast<u32x2*>(cc.out + opix * cc.out_cs + f * 16 + (lane >> 4) * 4) = __builtin_bit_cast(u32x2, h);
+          STG(u32x2, cc.out + opix * cc.out_cs + f * 16 + (lane >> 4) * 4, __builtin_bit_cast(u32x2, h), cc.x_out);
         }
       }
     }
@@ -1232,7 +1285,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
       const bool img = in && (unsigned)y < (unsigned)fs.new_h && (unsigned)x < (unsigned)fs.new_w;
       s_in = in;
       s_img = img;
-      graw = *reinterpret_cast<const u32x3*>(fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + y) * fs.src_w + x) * 3 : 0));
+      graw = LDG(u32x3, fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + y) * fs.src_w + x) * 3 : 0), a.x_img);
       return;
     }
 #pragma unroll
@@ -1241,7 +1294,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
       const bool in = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
       s_in |= (in ? 1u : 0u) << j;
       if (SRC == 0) {
-        stage[j] = *reinterpret_cast<const u32x4*>(a.in + (in ? ((size_t)(nx_n * a.H + ih) * a.W + iw) * a.in_cs : 0));
+        stage[j] = LDG(u32x4, a.in + (in ? ((size_t)(nx_n * a.H + ih) * a.W + iw) * a.in_cs : 0), a.x_in);
       } else {
         const int y = ih - fs.top, x = iw - fs.left;
         const bool img = in && (unsigned)y < (unsigned)fs.new_h && (unsigned)x < (unsigned)fs.new_w;
@@ -1250,20 +1303,20 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
         if (SRC == 1) {
           const uint8_t* p = f + (img ? ((size_t)(y * fs.step + fs.off) * fs.src_w + (x * fs.step + fs.off)) * 3 : 0);
           if (fs.step > 1) {  // a decimated pixel is never the last one of its row: one unaligned dword instead of 3 bytes
-            const unsigned v = *reinterpret_cast<const u32_unaligned*>(p);
+            const unsigned v = LDG(u32_unaligned, p, a.x_img);
 #pragma unroll
             for (int c = 0; c < 3; ++c) raw[j][c] = (v >> (8 * c)) & 0xffu;
           } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) raw[j][c] = p[c];
+            for (int c = 0; c < 3; ++c) raw[j][c] = LDG(uint8_t, p + c, a.x_img);
           }
         } else {
           const uint8_t* p0 = f + (img ? ((size_t)(2 * y) * fs.src_w + 2 * x) * 3 : 0);
           const uint8_t* p1 = p0 + (img ? (size_t)fs.src_w * 3 : 0);
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
-            raw[j][c] = p0[c];
-            raw[j][6 + c] = p1[c];
+            raw[j][c] = LDG(uint8_t, p0 + c, a.x_img);
+            raw[j][6 + c] = LDG(uint8_t, p1 + c, a.x_img);
           }
         }
       }
@@ -1468,16 +1521,16 @@ __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st
         const size_t row = img ? (size_t)fs.src_w * 3 : 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          gh[j][i] = *reinterpret_cast<const u32_unaligned*>(p + 4 * i);
-          gh[j][6 + i] = *reinterpret_cast<const u32_unaligned*>(p + row + 4 * i);
+          gh[j][i] = LDG(u32_unaligned, p + 4 * i, a.x_img);
+          gh[j][6 + i] = LDG(u32_unaligned, p + row + 4 * i, a.x_img);
         }
       } else if (DECIM) {
         const uint8_t* p = fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + y * fs.step + fs.off) * fs.src_w + x * fs.step + fs.off) * 3 : 0);
         const int ps = img ? fs.step * 3 : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) graw[j][i] = *reinterpret_cast<const u32_unaligned*>(p + i * ps);
+        for (int i = 0; i < 4; ++i) graw[j][i] = LDG(u32_unaligned, p + i * ps, a.x_img);
       } else {
-        const u32x3 g = *reinterpret_cast<const u32x3*>(fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + y) * fs.src_w + x) * 3 : 0));
+        const u32x3 g = LDG(u32x3, fs.bgr + (img ? ((size_t)(nx_n * fs.src_h + y) * fs.src_w + x) * 3 : 0), a.x_img);
         graw[j] = u32x4{g[0], g[1], g[2], 0};
       }
     }
@@ -1683,7 +1736,7 @@ __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st
           v = silu4(v);
         }
         const f16x4 h = __builtin_convertvector(v, f16x4);
-        *reinterpret_cast<u32x2*>(a.post_out + opix * a.post_out_cs + f * 16 + q * 4) = __builtin_bit_cast(u32x2, h);
+        STG(u32x2, a.post_out + opix * a.post_out_cs + f * 16 + q * 4, __builtin_bit_cast(u32x2, h), a.x_out);
       }
     }
   }
@@ -2101,6 +2154,27 @@ bool conv_chain_cat_ok(const ConvWeights& a, const ConvWeights& b, const ConvWei
   return !off && conv_chain_ok(a, b) && chain_cat_chunks(a, c2) > 0;
 }
 
+namespace {
+// extents of the tensors one launch touches, from the slice geometry (a slice's buffer holds pixels x cstride elements);
+// only the bounds-check build reads them
+BcExt ext_of(const void* p, size_t bytes) {
+  BcExt e;
+  e.lo = reinterpret_cast<const char*>(p);
+  e.hi = e.lo + (p ? bytes : 0);
+  return e;
+}
+void set_extents(ConvArgs& a, Slice in, Slice res, Slice out, const float* out_f32, const unsigned long long* clsmax,
+                 const UpSource* up, const FusedInput* fused) {
+  const size_t pin = (size_t)a.N * a.H * a.W, pout = (size_t)a.N * a.Ho * a.Wo;
+  a.x_in = ext_of(in.ptr, pin * in.cstride * 2);
+  a.x_res = ext_of(res.ptr, pout * res.cstride * 2);
+  a.x_out = out_f32 ? ext_of(out_f32, pout * a.Cout * 4) : ext_of(out.ptr, pout * out.cstride * 2);
+  a.x_cls = ext_of(clsmax, pout * 8);
+  a.x_in2 = up ? ext_of(up->src.ptr, (size_t)a.N * (a.H / 2) * (a.W / 2) * up->src.cstride * 2) : BcExt{};
+  a.x_img = fused ? ext_of(fused->bgr, (size_t)a.N * fused->src_h * fused->src_w * 3) : BcExt{};
+}
+}  // namespace
+
 int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, int N, int H, int W, Slice out,
                        bool residual, int act_a, int act_b, hipStream_t stream, const ConvWeights* cat_w, Slice cat_in,
                        Slice cat_out, int cat_act) {
@@ -2145,7 +2219,11 @@ int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, i
     cc.act = cat_act;
     cc.cat = cat_in.ptr + cat_in.coff;
     cc.cat_cs = cat_in.cstride;
+    cc.x_cat = ext_of(cat_in.ptr, (size_t)N * H * W * cat_in.cstride * 2);
+    cc.x_out = ext_of(cat_out.ptr, (size_t)N * H * W * cat_out.cstride * 2);
   }
+  a.x_in = a.x_res = ext_of(in.ptr, (size_t)N * H * W * in.cstride * 2);
+  a.x_out = ext_of(out.ptr, (size_t)N * H * W * out.cstride * 2);
   prof_start(EIOKU_PROF_CONV, stream);
   // (a second patch buffer was measured against an extra workgroup per CU: 77 vs 69 us at 160^2; single-buffered it is)
   int rc;
@@ -2200,6 +2278,8 @@ int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, cons
   a.post_out_cs = out.cstride;
   a.post_cout = post.cout;
   a.post_act = act2;
+  a.x_out = ext_of(out.ptr, (size_t)N * a.Ho * a.Wo * out.cstride * 2);
+  a.x_img = ext_of(f.bgr, (size_t)N * f.src_h * f.src_w * 3);
   StemArgs st{reinterpret_cast<const uint4*>(stem.d_w), stem.d_b, act0, H, W};
   FusedSrc fs{f.bgr, f.src_h, f.src_w, f.new_h, f.new_w, f.top, f.left, f.step, f.off};
   static bool attr_set = false;
@@ -2286,6 +2366,7 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
   a.in2 = up ? up->src.ptr + up->src.coff : nullptr;
   a.in2_cs = up ? up->src.cstride : 0;
   a.c_split = up ? up->c_split : 0;
+  set_extents(a, in, res, out, out_f32, clsmax, up, fused);
   prof_start(EIOKU_PROF_CONV, stream);
   int rc = EIOKU_OK;
   bool handled = false;
@@ -2354,6 +2435,55 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
 using namespace eioku;
 
 extern "C" {
+
+#ifdef EIOKU_BOUNDS_CHECK
+namespace {
+__global__ void k_bc_selftest(const unsigned* p, BcExt e, unsigned* sink) {
+  // one element inside the extent, one straddling its end, one before its start
+  unsigned v = LDG(unsigned, p, e);
+  v += LDG(unsigned, reinterpret_cast<const char*>(p) + (e.hi - e.lo) - 2, e);
+  v += LDG(unsigned, p - 1, e);
+  STG(unsigned, sink, v, e);  // a store outside the extent: counted, not performed
+}
+}  // namespace
+#endif
+
+// Bounds-check instrumentation.  violations: accesses outside their tensor since the last reset
+// (-1: this is not the bounds-check build); line: largest conv.hip source line of a violation.  selftest != 0 first
+// runs a kernel that makes exactly 3 violations on purpose (the net catches what it should).
+int eioku_debug_bounds(int* violations, int* line, int reset, int selftest) {
+  EIOKU_REQUIRE(violations && line, "NULL output");
+#ifdef EIOKU_BOUNDS_CHECK
+  EIOKU_REQUIRE_INIT();
+  if (selftest) {
+    unsigned* buf = nullptr;
+    EIOKU_HIP_CHECK(hipMalloc((void**)&buf, 64));
+    EIOKU_HIP_CHECK(hipMemset(buf, 0, 64));
+    hipLaunchKernelGGL(k_bc_selftest, dim3(1), dim3(1), 0, 0, buf + 4, ext_of(buf + 4, 16), buf + 12);
+    EIOKU_LAUNCH_CHECK();
+    EIOKU_HIP_CHECK(hipDeviceSynchronize());
+    unsigned sink = 1;
+    EIOKU_HIP_CHECK(hipMemcpy(&sink, buf + 12, 4, hipMemcpyDeviceToHost));
+    (void)hipFree(buf);
+    EIOKU_REQUIRE(sink == 0, "the bounds-check store went through (%u)", sink);
+  }
+  EIOKU_HIP_CHECK(hipDeviceSynchronize());
+  int h[4] = {0, 0, 0, 0};
+  EIOKU_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bc_flag), sizeof h));
+  *violations = h[0];
+  *line = h[1];
+  if (reset) {
+    const int z[4] = {0, 0, 0, 0};
+    EIOKU_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bc_flag), z, sizeof z));
+  }
+#else
+  (void)reset;
+  (void)selftest;
+  *violations = -1;
+  *line = 0;
+#endif
+  return EIOKU_OK;
+}
 
 int eioku_conv2d_f16(const void* in_nhwc, int n, int h, int w, int in_cstride, int in_coff, int cin,
                      const float* weight_oihw, const float* bias, int cout, int ksize, int stride,

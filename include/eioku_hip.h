@@ -165,6 +165,11 @@ int eioku_conv2d_f16(const void* in_nhwc, int n, int h, int w, int in_cstride, i
                      int act_silu, const void* residual, int res_cstride, int res_coff,
                      void* out_nhwc, int out_cstride, int out_coff, float* out_f32, void* stream);
 
+/* Bounds-check instrumentation of the conv family (libeioku_hip_bc.so = the same sources with -DEIOKU_BOUNDS_CHECK: every
+ * global access of an activation / residual / image / output tensor is compared with the tensor's extent, a violation is
+ * counted, not performed).  violations = -1 in the regular library.  selftest != 0: first make 3 violations on purpose. */
+int eioku_debug_bounds(int* violations, int* line, int reset, int selftest);
+
 /* YOLOv8 detector handle.  Replaces `YOLO(model_path); model.to(device)` + `model(frame, conf=..)`
  * of ModelManager.detect_objects / detect_faces (model_manager.py:252-254,270-275 / :346-348,
  * :364-369).  The graph is the Ultralytics yolov8 layout parameterised by its backbone widths
