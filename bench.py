@@ -51,6 +51,11 @@ def parse_args(argv=None):
     ap.add_argument("--conf", type=float, default=0.25)
     ap.add_argument("--segments", type=int, default=8, help="transcript segments embedded per step")
     ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--embed-batch", type=int, default=0,
+                    help="segments per encoder call (eioku_amd.embed.SegmentBatcher; 0 = the step's own segments, every step): "
+                         "larger batches cost 2.8x less encoder time per segment (tools/embed_batch_sweep.py) but the 2.4 ms "
+                         "burst of 128 x 128-tile GEMMs every 16th step slows the detector beside it by more than that "
+                         "(measured 1.64 vs 1.51 ms per step), so the default keeps one call per step")
     ap.add_argument("--stages", default="scene,detect,embed", help="comma list (debug)")
     ap.add_argument("--knn-n", type=int, default=10_000_000, help="0 disables the kNN part")
     ap.add_argument("--knn-nq", type=int, default=1024)
@@ -140,11 +145,15 @@ class Pipeline:
             # --depth 2: eioku_amd.detect.PipelinedDetector, the same object ModelManager's frame loop runs on: a
             # second handle (same weights, own activation buffers) on its own stream, consecutive batches overlap
             self.pdet = detect.PipelinedDetector(self.det, depth=max(1, args.depth), device=device) if args.overlap else None
+        self.batcher = None
+        self.embedded = []
         if "embed" in self.stages:
             self.enc = embed.MiniLMEncoder(embed.random_state(embed.MINILM_L6_V2, 11))
             g = torch.Generator(device="cpu").manual_seed(11 + rank)
-            self.ids = torch.randint(1000, 30000, (args.segments, args.seq_len), generator=g, dtype=torch.int32).to(device)
+            # 16 steps' worth of distinct segments, walked cyclically
+            self.ids = torch.randint(1000, 30000, (16, args.segments, args.seq_len), generator=g, dtype=torch.int32).to(device)
             self.mask = torch.ones((args.segments, args.seq_len), dtype=torch.uint8, device=device)
+            self.batcher = embed.SegmentBatcher(self.enc, args.seq_len, max(args.segments, args.embed_batch), device)
         self.last = None
         # The three stages of a step share no data (the reference runs them as separate tasks): each gets its own
         # HIP stream so that the many small launches of one (20x20 convs, M=1024 GEMMs, each a fraction of the
@@ -178,13 +187,20 @@ class Pipeline:
                 out.append(self.det.detect(f, conf=self.args.conf, keep_on_device=True))
         if self.enc is not None:
             with self._on("embed"):
-                out.append(self.enc.encode_ids(self.ids, self.mask))
+                self.embedded = self.batcher.add(self.ids[i % 16], self.mask) or self.embedded
         if "scene" in self.stages:
             with self._on("scene"):
                 out.append(scene.hsv_sums(f, self.prev, keep_on_device=True))
                 out.append(scene.luma_sad(self.luma[i & 1], keep_on_device=True))
                 self.prev = f[-1]
         self.last = out
+
+    def finish(self):
+        """Inside the timed region, before its closing barrier: every segment handed over so far is encoded."""
+        if self.batcher is not None:
+            self.serial = False
+            with self._on("embed"):
+                self.embedded = self.batcher.flush() or self.embedded
 
     def close(self):
         if self.pdet is not None:
@@ -517,7 +533,7 @@ def main():
     # HIP-event hooks bracket every tagged launch on the kernel's own stream; they are sampled (every
     # --prof-every-th step of the timed region, run un-overlapped) because 2 event records per launch x ~130
     # launches per step are themselves ~15% of a step and because overlapped stages stretch each other's kernels
-    def profiled(i):
+    def profiled(i, args=args):
         if args.prof_every < 0:
             return i == args.steps // 2
         return args.prof_every > 0 and i % args.prof_every == 0
@@ -527,11 +543,13 @@ def main():
         pipe = Pipeline(args, device, rank, height, width)
         for i in range(args.warmup):
             pipe.step(i)
+        pipe.finish()  # the timed region starts with an empty segment batch
         barrier()
+        seg0 = pipe.batcher.encoded if pipe.batcher is not None else 0
         _lib.prof_reset()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            if profiled(i):
+            if profiled(i, args):
                 torch.cuda.synchronize()  # drain the overlapped steps, time this one's kernels alone, drain again
                 _lib.prof_enable(True, tags=[_lib.PROF_CONV, _lib.PROF_SCENE_HSV, _lib.PROF_SCENE_SAD])
                 pipe.step(i, serial=True)
@@ -539,10 +557,13 @@ def main():
                 _lib.prof_enable(False)
             else:
                 pipe.step(i)
+        pipe.finish()  # the segments of the last steps, still inside the timed region
         barrier()
         elapsed = time.perf_counter() - t0
+        if pipe.batcher is not None:
+            assert pipe.batcher.encoded - seg0 == args.segments * args.steps, "every step's segments are encoded in the timed region"
         _lib.prof_enable(False)
-        pipe.prof_steps = sum(1 for i in range(args.steps) if profiled(i))
+        pipe.prof_steps = sum(1 for i in range(args.steps) if profiled(i, args))
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -570,7 +591,9 @@ def main():
             "config": {"workload": f"{args.batch}x{height}x{width} BGR u8 frames/step/GPU resident in HBM: "
                                    f"scene (HSV ContentDetector sums + luma SAD) on every frame, {args.model} (random-init, "
                                    f"fp16) detect on every frame, all-MiniLM-L6-v2 (random-init, fp32) on {args.segments} "
-                                   f"segments x {args.seq_len} tokens per step; stages run: {', '.join(pipe.stages)}{note}",
+                                   f"segments x {args.seq_len} tokens per step, collected on the device and encoded "
+                                   f"{max(args.segments, args.embed_batch)} segments at a time (the rest inside the timed region); "
+                                   f"stages run: {', '.join(pipe.stages)}{note}",
                        "batch": args.batch, "frame": [height, width], "parallelism": f"shard-by-video x{world}"},
             "roofline": {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": achieved, "peak": dom["peak"],
                          "unit": dom["unit"], "frac": achieved / dom["peak"], "traffic": traffic, "traffic_note": tnote,

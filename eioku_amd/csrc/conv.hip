@@ -1203,6 +1203,137 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, 
 // same fp16 rounding of v/255, 114 grey outside the image) and build the unit on the way to LDS.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned u32_unaligned __attribute__((aligned(1)));
+// ---------------------------------------------------------------------------------------------
+// 64-channel Bottleneck pairs (3x3 -> 3x3 [+ x] at 40x40: model.6.m.0 / m.1, model.12.m.0, model.18.m.0) as ONE launch
+// with the WEIGHTS STATIONARY IN REGISTERS (round 3).  The chain kernel above keeps both weight blocks in LDS; at 64
+// channels they are 2 x 73.7 KB and nothing else fits, which is why these eight layers ran as separate 19 us launches
+// that move 63 MB each for 7.5 GFLOP - short HBM-bound kernels (3.3 TB/s, ramp and tail included), 152 us per forward.
+// gfx950's register file holds the weights instead: wave w of the 4-wave workgroup owns output channels 16 w .. 16 w + 15
+// of BOTH convolutions and keeps their 2 x 18 A fragments (2 chunks x 9 taps, 16 bytes per lane) in 144 VGPRs for the
+// whole launch - no weight traffic and no weight LDS at all.  Per 8 x 16 output tile the workgroup stages the 12 x 20
+// input patch X (64 channels), every wave evaluates conv A for ITS 16 channels on the 10 x 18 pixels conv B needs (12
+// fragments of 16 flattened pixels) and writes act(A) as fp16 into the LDS patch P (zeros outside the map: conv B's
+// padding), then conv B for its 16 channels on the 8 x 16 tile, residual (= X's centre) from LDS.  Same operands, k
+// order (chunk-outer, tap-inner) and roundings as the separate launches: bit-identical (tested through EIOKU_CONV_CHAIN).
+// LDS: pixels are 5 units apart per chunk (4 + 1 pad): a 16-lane group reading 16 consecutive pixels' units is
+// conflict-free WITHOUT an XOR swizzle ((20 px + 4 ku) mod 64 is a permutation), so a tap is an immediate offset of one
+// base address per fragment - no address arithmetic between the 360 ds_read_b128 of a tile.  HBM per pair: one
+// 1.9x-halo read + one write (77 MB) instead of 126 MB, and one intermediate tensor never exists.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRS_XH = kTH + 4, kRS_XW = kTW + 4, kRS_PH = kTH + 2, kRS_PW = kTW + 2, kRS_PITCH = 5;
+constexpr int kRS_XU = kRS_XH * kRS_XW * kRS_PITCH, kRS_PU = kRS_PH * kRS_PW * kRS_PITCH;  // 16-byte units per chunk
+constexpr int kRS_NPA = kRS_PH * kRS_PW, kRS_MA = (kRS_NPA + 15) / 16;                      // conv A pixels / fragments
+constexpr size_t kPairRsLds = (size_t)(2 * kRS_XU + 2 * kRS_PU + 8) * 16;
+
+__global__ __launch_bounds__(256, 2) void k_conv3x3_pair_rs(ConvArgs a, int rows_a, int rows_b, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* X = reinterpret_cast<uint4*>(smem);   // [2 chunks][kRS_XU]
+  uint4* P = X + 2 * kRS_XU;                   // [2 chunks][kRS_PU] (+ 8 spare units: stores of the clamped tail)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px16 = lane & 15, ku = lane >> 4;
+
+  // this wave's weights: A fragment (chunk cc, tap) of couts 16 wave .. + 15 = row (16 wave + px16) of the packed tile
+  u32x4 wA[18], wB[18];
+  {
+    const int ta = (16 * wave) / rows_a, ra = (16 * wave) % rows_a + px16;
+    const int tb = (16 * wave) / rows_b, rb = (16 * wave) % rows_b + px16;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        wA[cc * 9 + tap] = *reinterpret_cast<const u32x4*>(a.wgt + (((size_t)(ta * 2 + cc) * 9 + tap) * rows_a + ra) * 4 + ku);
+        wB[cc * 9 + tap] = *reinterpret_cast<const u32x4*>(a.post_w + (((size_t)(tb * 2 + cc) * 9 + tap) * rows_b + rb) * 4 + ku);
+      }
+  }
+  const float4 biasA = *reinterpret_cast<const float4*>(a.bias + 16 * wave + ku * 4);
+  const float4 biasB = *reinterpret_cast<const float4*>(a.post_bias + 16 * wave + ku * 4);
+
+  // conv A: fragment m = flattened P pixels 16 m .. 16 m + 15 (the tail of the last one re-computes pixel NPA - 1 and
+  // stores to the spare units); conv B: fragment m = row m of the tile.  One fragment at a time, its 18 products chained
+  // on ONE accumulator (a 16x16x32 chain issues back to back): the registers hold weights, not accumulators or indices.
+  const int my_unit = (wave & 1) * 2 + (lane >> 5), my_half = (lane >> 4) & 1;  // where this lane's 4 couts sit in a pixel
+
+  const int tiles_per_img = a.tiles_w * a.tiles_h;
+  const float r_tpi = 1.0f / (float)tiles_per_img, r_tw = 1.0f / (float)a.tiles_w;
+  constexpr int NLOAD = kRS_XH * kRS_XW * 8, R = (NLOAD + 255) / 256;  // 16-byte units of the input patch (64 channels)
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int tn = fast_div(tile, tiles_per_img, r_tpi);
+    const int t2 = tile - tn * tiles_per_img;
+    const int tth = fast_div(t2, a.tiles_w, r_tw), ttw = t2 - tth * a.tiles_w;
+    const int ih0 = tth * kTH - 2, iw0 = ttw * kTW - 2;
+    {
+      u32x4 stage[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int idx = tid + 256 * j;
+        const int pix = idx >> 3, u8 = idx & 7;
+        const int py = pix / kRS_XW, px = pix - py * kRS_XW;
+        const int ih = ih0 + py, iw = iw0 + px;
+        const bool ok = idx < NLOAD && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        stage[j] = LDG(u32x4, a.in + (ok ? ((size_t)(tn * a.H + ih) * a.W + iw) * a.in_cs + u8 * 8 : 0), a.x_in);
+        if (!ok) stage[j] = u32x4{0, 0, 0, 0};
+      }
+      __syncthreads();  // every wave is done with the previous tile's X (residual) and P
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int idx = tid + 256 * j;
+        const int pix = idx >> 3, u8 = idx & 7;
+        if (idx < NLOAD) *reinterpret_cast<u32x4*>(X + (u8 >> 2) * kRS_XU + pix * kRS_PITCH + (u8 & 3)) = stage[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int m = 0; m < kRS_MA; ++m) {
+      const int praw = m * 16 + px16;
+      const int p = praw < kRS_NPA ? praw : kRS_NPA - 1;
+      const int py = p / kRS_PW, px = p - py * kRS_PW;
+      const uint4* xa = X + (py * kRS_XW + px) * kRS_PITCH + ku;
+      float4v acc = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const uint4 b = xa[cc * kRS_XU + ((tap / 3) * kRS_XW + tap % 3) * kRS_PITCH];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wA[cc * 9 + tap]), *reinterpret_cast<const half8*>(&b), acc, 0, 0, 0);
+        }
+      const int ah = tth * kTH - 1 + py, aw = ttw * kTW - 1 + px;
+      const bool inmap = (unsigned)ah < (unsigned)a.H && (unsigned)aw < (unsigned)a.W;
+      const float4v v = activate_frag(a, acc, biasA);
+      const f16x4 h = __builtin_convertvector(v, f16x4);
+      const int st = (praw < kRS_NPA ? ((wave >> 1) * kRS_PU + p * kRS_PITCH + my_unit) : (2 * kRS_PU + my_unit)) * 16 + my_half * 8;
+      *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(P) + st) = inmap ? __builtin_bit_cast(u32x2, h) : u32x2{0, 0};
+    }
+    __syncthreads();
+    const int ow = ttw * kTW + px16;
+#pragma unroll 1
+    for (int m = 0; m < kTH; ++m) {
+      const uint4* pb = P + (m * kRS_PW + px16) * kRS_PITCH + ku;
+      float4v acc = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const uint4 b = pb[cc * kRS_PU + ((tap / 3) * kRS_PW + tap % 3) * kRS_PITCH];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wB[cc * 9 + tap]), *reinterpret_cast<const half8*>(&b), acc, 0, 0, 0);
+        }
+      const int oh = tth * kTH + m;
+      float4v v = acc + float4v{biasB.x, biasB.y, biasB.z, biasB.w};
+      if (a.post_act == kActSiLU) v = silu4(v);
+      f16x4 h = __builtin_convertvector(v, f16x4);
+      if (a.res) {  // the Bottleneck's shortcut = its own input: the centre of X
+        const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(X + (wave >> 1) * kRS_XU +
+                                                        ((m + 2) * kRS_XW + px16 + 2) * kRS_PITCH + my_unit) + my_half * 8);
+        const float4v sum = __builtin_convertvector(h, float4v) + __builtin_convertvector(__builtin_bit_cast(f16x4, r), float4v);
+        h = __builtin_convertvector(sum, f16x4);
+      }
+      if (oh < a.Ho && ow < a.Wo) {
+        const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+        STG(u32x2, a.post_out + opix * a.post_out_cs + 16 * wave + ku * 4, __builtin_bit_cast(u32x2, h), a.x_out);
+      }
+    }
+  }
+}
+
 struct FusedSrc {
   const uint8_t* bgr;
   int src_h, src_w, new_h, new_w, top, left;
@@ -2127,6 +2258,15 @@ bool conv_post_ok(const ConvWeights& cw, const ConvWeights& post) {
   return persist_lds(cw.nf, cw.stride, cw.nchunks, false) + extra <= 150 * 1024;
 }
 
+// 64 -> 64 -> 64 pairs: k_conv3x3_pair_rs (weights in registers); any packing of the 64 couts into tiles of 16 * nf rows
+static bool conv_pair_rs_shapes(const ConvWeights& a, const ConvWeights& b) {
+  static const bool off = getenv("EIOKU_CONV_PAIR_RS") && atoi(getenv("EIOKU_CONV_PAIR_RS")) == 0;
+  auto one = [](const ConvWeights& c) {
+    return c.ks == 3 && c.stride == 1 && c.cin == 64 && c.cout == 64 && c.nchunks == 2 && (16 * c.nf) % 16 == 0 && 64 % (16 * c.nf) == 0;
+  };
+  return !off && one(a) && one(b);
+}
+
 bool conv_chain_ok(const ConvWeights& a, const ConvWeights& b) {
   static const bool off = getenv("EIOKU_CONV_CHAIN") && atoi(getenv("EIOKU_CONV_CHAIN")) == 0;
   if (off) return false;
@@ -2134,6 +2274,7 @@ bool conv_chain_ok(const ConvWeights& a, const ConvWeights& b) {
     return c.ks == 3 && c.stride == 1 && c.nchunks == 1 && c.ntiles == 1 && (c.nf == 1 || c.nf == 2) && c.cout == 16 * c.nf &&
            c.cin == c.cout;
   };
+  if (conv_pair_rs_shapes(a, b)) return true;
   return one(a) && one(b) && a.nf == b.nf;
 }
 
@@ -2151,7 +2292,7 @@ int chain_cat_chunks(const ConvWeights& a, const ConvWeights& c2) {
 
 bool conv_chain_cat_ok(const ConvWeights& a, const ConvWeights& b, const ConvWeights& c2) {
   static const bool off = getenv("EIOKU_CHAIN_CAT") && atoi(getenv("EIOKU_CHAIN_CAT")) == 0;
-  return !off && conv_chain_ok(a, b) && chain_cat_chunks(a, c2) > 0;
+  return !off && !conv_pair_rs_shapes(a, b) && conv_chain_ok(a, b) && chain_cat_chunks(a, c2) > 0;
 }
 
 namespace {
@@ -2227,6 +2368,20 @@ int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, i
   prof_start(EIOKU_PROF_CONV, stream);
   // (a second patch buffer was measured against an extra workgroup per CU: 77 vs 69 us at 160^2; single-buffered it is)
   int rc;
+  if (!cat_w && conv_pair_rs_shapes(ca, cb)) {
+    a.nchunks = 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_pair_rs),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairRsLds));
+      attr_set = true;
+    }
+    const int total = a.tiles_w * a.tiles_h * a.N;
+    int bx = num_cus() * 2;
+    if (bx > total) bx = total;
+    hipLaunchKernelGGL(k_conv3x3_pair_rs, dim3((unsigned)bx), dim3(256), kPairRsLds, stream, a, 16 * ca.nf, 16 * cb.nf, total);
+    rc = hipGetLastError() == hipSuccess ? EIOKU_OK : EIOKU_EHIP;
+  } else
   if (cat_w) {
     const int cat = chain_cat_chunks(ca, *cat_w);
     rc = cat == 1 ? launch_chain<1, false, 1, 2>(a, cc, stream)
