@@ -72,7 +72,8 @@ for (name, cout, cin, k, s) in tab:
     skip = nl - 1
     fl = 2.0 * px_out * cout * cin * k * k
     us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-XX
+    m_ = re.search(r'(k_conv\w+<[^>]*>)', r['Kernel_Name'])
+    kn = m_.group(1) if m_ else ('k_conv3x3_pair_rs' if 'pair_rs' in r['Kernel_Name'] else 'k_conv_stem_chain')
     tot_t += us; tot_b += by; tot_f += fl
     print(f"{name:28s} {cin:4d}->{cout:4d} k{k}s{s} @{hout:3d} {kn:28s} {int(r['Grid_Size_X'])//256:5d}x{r['Grid_Size_Y']:>3s} {us:7.1f} {by/1e6:7.1f} {by/us/1e3:6.0f} {fl/us/1e6:6.1f}")
 print(f"TOTAL {tot_t:.1f} us, {tot_b/1e9:.2f} GB -> {tot_b/tot_t/1e3:.0f} GB/s, {tot_f/1e9:.1f} GFLOP -> {tot_f/tot_t/1e6:.1f} TF/s")
