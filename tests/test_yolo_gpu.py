@@ -399,6 +399,13 @@ def test_fused_3x3_1x1_pairs_are_bit_identical_to_separate_launches(gpu, variant
     assert len(outs["1"]) == 6
     for a, b in zip(outs["1"], outs["0"]):
         assert a.dtype == np.float32 and np.array_equal(a, b)
+    # the opt-in register-stationary Bottleneck pairs (k_conv3x3_pair_rs: 64-channel pairs at 40 x 40): same bytes too
+    path = tmp_path / "heads_rs.npz"
+    env = dict(os.environ, EIOKU_CONV_PAIR_RS="1")
+    subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=env, timeout=300)
+    with np.load(path) as z:
+        for k, b in zip(z.files, outs["0"]):
+            assert np.array_equal(z[k], b)
 
 
 @pytest.mark.parametrize("variant,h,w", [("n", 640, 640), ("m", 1080, 1920), ("n", 1080, 1920)])
