@@ -941,11 +941,15 @@ __global__ __launch_bounds__(NW * 64) void k_lscan(LScanArgs a) {
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
         const f32x16& c = acc[i];
-        float m01 = fmaxf(fmaxf(c[0], c[1]), c[2]), m23 = fmaxf(fmaxf(c[3], c[4]), c[5]);
-        float m45 = fmaxf(fmaxf(c[6], c[7]), c[8]), m67 = fmaxf(fmaxf(c[9], c[10]), c[11]);
-        float m89 = fmaxf(fmaxf(c[12], c[13]), c[14]);
-        const float mx = fmaxf(fmaxf(fmaxf(m01, m23), fmaxf(m45, m67)), fmaxf(m89, c[15]));
-        if (mx >= hxmin[i] + thr && act[i]) {
+        // the tile test on the products' bit patterns as signed integers (see k_l2_scan: 8 v_max3_i32, no canonicalisation);
+        // T <= 0 or NaN (no bound for the query) takes the exact per-row test
+        auto ib = [&](int r) { return __float_as_int(c[r]); };
+        const int i01 = max(max(ib(0), ib(1)), ib(2)), i23 = max(max(ib(3), ib(4)), ib(5));
+        const int i45 = max(max(ib(6), ib(7)), ib(8)), i67 = max(max(ib(9), ib(10)), ib(11));
+        const int i89 = max(max(ib(12), ib(13)), ib(14));
+        const int imx = max(max(max(i01, i23), i45), max(max(i67, i89), ib(15)));
+        const float T = hxmin[i] + thr;
+        if ((!(T > 0.f) || imx >= __float_as_int(T)) && act[i]) {
           const int r0 = pos0 + (wave * RT + i) * 32;
           int h4 = 4 * half;
           asm volatile("" : "+v"(h4));

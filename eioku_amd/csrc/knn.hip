@@ -922,13 +922,19 @@ __global__ __launch_bounds__(NW * 64) void k_l2_scan(ScanArgs a) {
       for (int i = 0; i < RT; ++i) {
         const f32x16& c = acc[i];
         const float thr_q = hcq - sqq * sxm[i];
-        // (fmaxf costs a canonicalising v_max_f32 x, x per accumulator; v_max3_f32 in inline asm does not, but the
-        // compiler's hazard recogniser does not see an asm's read of a just-written MFMA result: wrong values, reverted)
-        float m01 = fmaxf(fmaxf(c[0], c[1]), c[2]), m23 = fmaxf(fmaxf(c[3], c[4]), c[5]);
-        float m45 = fmaxf(fmaxf(c[6], c[7]), c[8]), m67 = fmaxf(fmaxf(c[9], c[10]), c[11]);
-        float m89 = fmaxf(fmaxf(c[12], c[13]), c[14]);
-        const float mx = fmaxf(fmaxf(fmaxf(m01, m23), fmaxf(m45, m67)), fmaxf(m89, c[15]));
-        if (mx >= hxmin[i] + thr_q && own[i]) {
+        // "does any of the 16 products reach T = hxmin + thr_q?"  on the products' BIT PATTERNS as signed integers (r3):
+        // for T > 0 a product >= T is a positive float >= T, and positive floats order like their bits; negative products
+        // have the sign bit set = negative integers, below every positive T.  8 v_max3_i32 and no float canonicalisation
+        // (fmaxf cost a v_max_f32 x, x per accumulator on top of the maxima: ~25 VALU per tile instead of 9; a
+        // v_max3_f32 in inline asm was tried in r2 and reverted: the hazard recogniser does not see an asm's read of a
+        // just-written MFMA result).  T <= 0 (no bound for the query) takes the per-row test, which is exact.
+        auto ib = [&](int r) { return __float_as_int(c[r]); };
+        const int i01 = max(max(ib(0), ib(1)), ib(2)), i23 = max(max(ib(3), ib(4)), ib(5));
+        const int i45 = max(max(ib(6), ib(7)), ib(8)), i67 = max(max(ib(9), ib(10)), ib(11));
+        const int i89 = max(max(ib(12), ib(13)), ib(14));
+        const int imx = max(max(max(i01, i23), i45), max(max(i67, i89), ib(15)));
+        const float T = hxmin[i] + thr_q;
+        if ((!(T > 0.f) || imx >= __float_as_int(T)) && own[i]) {
           const int qi = qt * 32 + col;
           int h4 = 4 * half;
           asm volatile("" : "+v"(h4));  // keeps the 16 row offsets from being precomputed into registers that live across the loop
