@@ -26,13 +26,40 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
+
+// round-to-nearest-even to bf16, result in the upper 16 bits (finite inputs)
+__device__ __forceinline__ unsigned bf16_rne_bits(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+}
+
+// hi = RNE(v) (so |v - hi| <= 2^-9 |v| and the difference is exact in fp32), lo = RNE(v - hi): v = hi + lo up to
+// 2^-18 |v|, and the dropped lo.lo products are 2^-18 relative as well -- four times tighter than truncation,
+// which left the encoder's output 2.06e-5 off against a 2.0e-5 bar
+__device__ __forceinline__ void split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const unsigned ha = bf16_rne_bits(a), hb = bf16_rne_bits(b);
+  hi = (ha >> 16) | hb;
+  lo = (bf16_rne_bits(a - __uint_as_float(ha)) >> 16) | bf16_rne_bits(b - __uint_as_float(hb));
+}
+
+// one value -> its two terms (the same split as split_bf16_pair), for the producers that hand a GEMM its A operand as planes
+__device__ __forceinline__ void split_bf16_one(float a, unsigned short& hi, unsigned short& lo) {
+  const unsigned ha = bf16_rne_bits(a);
+  hi = (unsigned short)(ha >> 16);
+  lo = (unsigned short)(bf16_rne_bits(a - __uint_as_float(ha)) >> 16);
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm helpers: one wave per token row, H <= 1024, H % 64 == 0
 // ---------------------------------------------------------------------------------------------
 template <int MAXV>
 __device__ __forceinline__ void wave_layernorm(float (&x)[MAXV], int nv, int H, const float* __restrict__ g,
                                                const float* __restrict__ b, float eps, float* __restrict__ out,
-                                               int lane) {
+                                               int lane, unsigned short* __restrict__ ohi = nullptr,
+                                               unsigned short* __restrict__ olo = nullptr) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
@@ -54,14 +81,17 @@ __device__ __forceinline__ void wave_layernorm(float (&x)[MAXV], int nv, int H, 
   for (int i = 0; i < MAXV; ++i)
     if (i < nv) {
       const int c = lane + 64 * i;
-      out[c] = (x[i] - mean) * rstd * g[c] + b[c];
+      const float y = (x[i] - mean) * rstd * g[c] + b[c];
+      out[c] = y;
+      if (ohi) split_bf16_one(y, ohi[c], olo[c]);  // the next GEMM's A operand, already in its two bf16 terms
     }
 }
 
 __global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ ids, int T, int S, int H, int vocab,
                                                   const float* __restrict__ wemb, const float* __restrict__ pemb,
                                                   const float* __restrict__ temb, const float* __restrict__ g,
-                                                  const float* __restrict__ b, float eps, float* __restrict__ out) {
+                                                  const float* __restrict__ b, float eps, float* __restrict__ out,
+                                                  unsigned short* __restrict__ ohi, unsigned short* __restrict__ olo) {
   const int lane = threadIdx.x & 63;
   const int t = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (t >= T) return;
@@ -76,7 +106,8 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ id
       const int c = lane + 64 * i;
       x[i] = (wemb[(size_t)id * H + c] + temb[c]) + pemb[(size_t)pos * H + c];
     }
-  wave_layernorm<16>(x, nv, H, g, b, eps, out + (size_t)t * H, lane);
+  wave_layernorm<16>(x, nv, H, g, b, eps, out + (size_t)t * H, lane, ohi ? ohi + (size_t)t * H : nullptr,
+                     ohi ? olo + (size_t)t * H : nullptr);
 }
 
 // Fixed-width variant (H = 64*NV): every load of the row (up to 4 split-K planes, bias, residual) is issued
@@ -84,7 +115,8 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int32_t* __restrict__ id
 template <int NV>
 __global__ __launch_bounds__(256) void k_add_ln_fixed(const float* __restrict__ a, int nsplit, const float* __restrict__ abias,
                                                       const float* __restrict__ r, int T, const float* __restrict__ g,
-                                                      const float* __restrict__ b, float eps, float* __restrict__ out) {
+                                                      const float* __restrict__ b, float eps, float* __restrict__ out,
+                                                      unsigned short* __restrict__ ohi, unsigned short* __restrict__ olo) {
   constexpr int H = 64 * NV;
   const int lane = threadIdx.x & 63;
   const int t = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -111,12 +143,14 @@ __global__ __launch_bounds__(256) void k_add_ln_fixed(const float* __restrict__ 
     if (abias) v += bv[i];
     x[i] = v + rv[i];
   }
-  wave_layernorm<NV>(x, NV, H, g, b, eps, out + (size_t)t * H, lane);
+  wave_layernorm<NV>(x, NV, H, g, b, eps, out + (size_t)t * H, lane, ohi ? ohi + (size_t)t * H : nullptr,
+                     ohi ? olo + (size_t)t * H : nullptr);
 }
 
 __global__ __launch_bounds__(256) void k_add_ln(const float* __restrict__ a, int nsplit, const float* __restrict__ abias,
                                                 const float* __restrict__ r, int T, int H, const float* __restrict__ g,
-                                                const float* __restrict__ b, float eps, float* __restrict__ out) {
+                                                const float* __restrict__ b, float eps, float* __restrict__ out,
+                                                unsigned short* __restrict__ ohi, unsigned short* __restrict__ olo) {
   const int lane = threadIdx.x & 63;
   const int t = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (t >= T) return;
@@ -132,7 +166,8 @@ __global__ __launch_bounds__(256) void k_add_ln(const float* __restrict__ a, int
       if (abias) v += abias[c];
       x[i] = v + r[(size_t)t * H + c];
     }
-  wave_layernorm<16>(x, nv, H, g, b, eps, out + (size_t)t * H, lane);
+  wave_layernorm<16>(x, nv, H, g, b, eps, out + (size_t)t * H, lane, ohi ? ohi + (size_t)t * H : nullptr,
+                     ohi ? olo + (size_t)t * H : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -140,7 +175,33 @@ __global__ __launch_bounds__(256) void k_add_ln(const float* __restrict__ a, int
 // ---------------------------------------------------------------------------------------------
 constexpr int kBK = 32;
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf to <= 1.7 ulp (checked against 40-digit values on 60 k points of [-6, 6] and a normal sample in fp32 arithmetic:
+// tools/fit_erf.py, which also derived the minimax coefficients).  |a| <= 0.9277: a + a p(a^2); beyond: 1 - exp(t q(t) - t),
+// t clamped to 4 (erf = 1 in fp32 from 3.92).  Both sides are evaluated and selected - lanes of a wave differ anyway -
+// in ~22 instructions; the library erff costs ~40, and the GELU epilogue of the FFN1 GEMM (100 M values per 512-segment
+// batch) was its longest phase: 255 of 498 us with loads and MFMAs ablated away (profiles/r03_gemm_ablation.txt).
+__device__ __forceinline__ float erf_poly(float a) {
+  const float t = fabsf(a), s = a * a;
+  float r = -5.987081095e-04f;
+  r = fmaf(r, s, 4.992952105e-03f);
+  r = fmaf(r, s, -2.676688507e-02f);
+  r = fmaf(r, s, 1.128183827e-01f);
+  r = fmaf(r, s, -3.761249781e-01f);
+  r = fmaf(r, s, 1.283791512e-01f);
+  const float small = fmaf(r, a, a);
+  const float tc = fminf(t, 4.0f);
+  float q = -1.620942385e-05f;
+  q = fmaf(q, tc, 3.676992783e-04f);
+  q = fmaf(q, tc, -3.796639154e-03f);
+  q = fmaf(q, tc, 2.400766313e-02f);
+  q = fmaf(q, tc, -1.064029485e-01f);
+  q = fmaf(q, tc, -6.351379156e-01f);
+  q = fmaf(q, tc, -1.286272407e-01f);
+  const float big = copysignf(1.0f - __expf(fmaf(q, tc, -tc)), a);
+  return t > 0.927734375f ? big : small;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_poly(x * 0.70710678118654752440f)); }
 
 // BM x BN output tile per 4-wave workgroup (waves 2 x 2, each (BM/2) x (BN/2) = MI x NI MFMA tiles).
 // 128x128 for large M (MFMA-bound); 64x64 when M is small so that a batch of a few segments still
@@ -263,7 +324,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ A
 // transposition, no LDS round trip for P.  128 MFMAs per wave instead of ~12 k scalar FMAs per lane: 21 -> ~8 us.
 // Q / K columns are XOR-swizzled by the row in LDS (a column read is then conflict-free); rows >= S are zero, mask 0.
 __global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict__ qkv, const uint8_t* __restrict__ mask, int S,
-                                                        int H, float* __restrict__ ctx) {
+                                                        int H, float* __restrict__ ctx, unsigned short* __restrict__ chi,
+                                                        unsigned short* __restrict__ clo) {
   constexpr int SP = 128, QS = 32;
   __shared__ __attribute__((aligned(16))) float sQ[SP * QS];
   __shared__ __attribute__((aligned(16))) float sK[SP * QS];
@@ -354,7 +416,19 @@ __global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict_
   const int qi = q0 + c;
   if (qi >= S) return;
   const float rl = l > 0.f ? 1.0f / l : 0.f;  // fully masked segment -> zeros (its pooled vector is 0 anyway)
-  float* op = ctx + (row0 + qi) * (size_t)H + h * 32;
+  const size_t o0 = (row0 + qi) * (size_t)H + h * 32;
+  if (chi) {  // the out-projection GEMM is the only reader: hand it the two bf16 terms instead of fp32 (same bytes)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      unsigned h0, l0, h1, l1;
+      split_bf16_pair(o[4 * g] * rl, o[4 * g + 1] * rl, h0, l0);
+      split_bf16_pair(o[4 * g + 2] * rl, o[4 * g + 3] * rl, h1, l1);
+      *reinterpret_cast<u32x2b*>(chi + o0 + 8 * g + 4 * half) = u32x2b{h0, h1};
+      *reinterpret_cast<u32x2b*>(clo + o0 + 8 * g + 4 * half) = u32x2b{l0, l1};
+    }
+    return;
+  }
+  float* op = ctx + o0;
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     *reinterpret_cast<f32x4*>(op + 8 * g + 4 * half) = f32x4{o[4 * g] * rl, o[4 * g + 1] * rl, o[4 * g + 2] * rl, o[4 * g + 3] * rl};
@@ -629,6 +703,9 @@ struct eioku_bert {
   float* x = nullptr; float* y = nullptr; float* qkv = nullptr; float* ctx = nullptr; float* mid = nullptr;
   size_t x_cap = 0, y_cap = 0, qkv_cap = 0, ctx_cap = 0, mid_cap = 0;
   float* d_out = nullptr; size_t out_cap = 0;
+  // activations as bf16 hi | lo planes for the GEMMs that read them (x, ctx, mid): [2][T][width] each
+  unsigned short* xp = nullptr; unsigned short* cp = nullptr; unsigned short* mp = nullptr;
+  size_t xp_cap = 0, cp_cap = 0, mp_cap = 0;
   double flops_last = 0;
   // GEMM weights pre-split into bf16 hi / lo planes (same RNE split the kernel applies on the fly), per layer
   // [qkv | out | ffn1 | ffn2]; rebuilt lazily after set_tensor
@@ -749,25 +826,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_s(const float* __restrict__
 // a . w ~ a_hi.w_hi + a_lo.w_hi + a_hi.w_lo runs as 3 v_mfma_f32_32x32x16_bf16 per 16 k (96 cycles instead of 512),
 // accumulated in fp32.  Per-product error ~2^-16 relative; the encoder's outputs stay within the path's 1e-4 bar
 // (tests/test_bert_gpu.py, float64 oracle).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
-
-// round-to-nearest-even to bf16, result in the upper 16 bits (finite inputs)
-__device__ __forceinline__ unsigned bf16_rne_bits(float v) {
-  const unsigned u = __float_as_uint(v);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-}
-
-// hi = RNE(v) (so |v - hi| <= 2^-9 |v| and the difference is exact in fp32), lo = RNE(v - hi): v = hi + lo up to
-// 2^-18 |v|, and the dropped lo.lo products are 2^-18 relative as well -- four times tighter than truncation,
-// which left the encoder's output 2.06e-5 off against a 2.0e-5 bar
-__device__ __forceinline__ void split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
-  const unsigned ha = bf16_rne_bits(a), hb = bf16_rne_bits(b);
-  hi = (ha >> 16) | hb;
-  lo = (bf16_rne_bits(a - __uint_as_float(ha)) >> 16) | bf16_rne_bits(b - __uint_as_float(hb));
-}
-
 // weights -> bf16 hi / lo planes, once per load: the GEMM then copies 8 + 8 bytes instead of splitting 16
 __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ w, size_t npairs, unsigned* __restrict__ hi,
                                                       unsigned* __restrict__ lo) {
@@ -780,26 +838,48 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
 }
 
 // WMT x WNT: 32x32 MFMA tiles per wave (the workgroup's tile is 64 WMT x 64 WNT).  1 x 1 for the small-M ingest path
-// (more workgroups); 2 x 2 for M >= 8192: 8 LDS fragment reads per 12 MFMAs instead of 16, and every activation value
-// is split into its bf16 terms by N / 128 workgroups instead of N / 64 (the split's VALU ran level with the MFMAs).
-template <int EPI, bool WS, int BKS = 128, int WMT = 1, int WNT = 1>
-__global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ A, int lda, const float* __restrict__ W,
+// (more workgroups); 2 x 2 for M >= 8192: 8 LDS fragment reads per 12 MFMAs instead of 16.  Stages are 64 deep.
+//
+// Operands: W always as the bf16 hi / lo planes k_split_planes wrote at load time.  AS: the A operand arrives as planes
+// too, written by its producer (LayerNorm, attention, the GELU epilogue below: `Chi` / `Clo` non-null = write planes
+// instead of fp32 C).  The split is the same function of the same fp32 value wherever it runs, so the results are
+// bit-identical to splitting in the staging threads (AS = false, kept for a caller without planes).
+//
+// LDS image: a row is 16 slots of 16 B = [8 k-units of the hi plane | 8 of the lo plane]; slot(row, unit, plane) =
+// (unit ^ (row & 7)) | ((plane ^ ((row >> 3) & 1)) << 3): the 16 rows a ds_read_b128 lane group touches fall on 16
+// different slots (the r2 layout used 8 of them: 2-way conflicts on every fragment read, a third of the LDS cycles in
+// profiles/r03_pmc_gemm_ffn1_before.txt).
+//
+// Tile order: workgroups i, i + 8, i + 16 ... share an XCD (and its L2); they walk the N tiles of ONE row block before
+// the next, so a row block's A panel is fetched from HBM once and hit in L2 by the other N / BN - 1 workgroups.  With
+// blockIdx.x = row block (r2) every N tile re-streamed the whole A operand: 1.2 GB fetched for a 100 MB operand in FFN1,
+// L2 hit rate 39 %.
+template <int EPI, int WMT = 1, int WNT = 1, bool AS = false, int WGM = 2>
+__global__ __launch_bounds__(128 * WGM, WGM == 2 ? 2 : 1) void k_gemm_bf_s(const float* __restrict__ A, int lda,
                                                       const unsigned short* __restrict__ Whi,
                                                       const unsigned short* __restrict__ Wlo,
                                                       const float* __restrict__ bias, float* __restrict__ C, int ldc,
-                                                      int M, int N, int K, int kstages) {
-  constexpr int BM = 64 * WMT, BN = 64 * WNT;
-  constexpr int F4R = BKS / 4, RSTEP = 256 / F4R;  // float4 per staged row; rows covered by one pass of the 256 threads
-  constexpr int PPR = BKS / 8;   // 8-k units per row and plane
-  constexpr int UPR = 2 * PPR;   // [hi plane | lo plane]
-  constexpr int RA = BM * (BKS / 4) / 256, RW = BN * (BKS / 4) / 256;  // float4 per thread and stage
+                                                      int M, int N, int K, int kstages,
+                                                      const unsigned short* __restrict__ Ahi,
+                                                      const unsigned short* __restrict__ Alo,
+                                                      unsigned short* __restrict__ Chi, unsigned short* __restrict__ Clo) {
+  // WGM x 2 waves: the row block is 32 WMT WGM rows.  WGM = 4 (8 waves, 256 x 128 tiles, a quarter less L2 -> LDS traffic per
+  // MFMA, one workgroup per CU) measured level with 2 (223 vs 227 us per GEMM: profiles/r03_gemm_ablation.txt) and is not
+  // dispatched
+  constexpr int BKS = 64, BM = 32 * WGM * WMT, BN = 64 * WNT, UPR = 16, NT = 128 * WGM, RPP = NT / 16;  // rows per staging pass
+  constexpr int RA = BM / RPP, RW = BN / RPP;  // 16-byte loads per thread and stage (plane route), float4s on the fp32 route
   extern __shared__ __attribute__((aligned(16))) u32x4b sgb[];
   u32x4b* sA = sgb;              // [BM][UPR]
   u32x4b* sW = sgb + BM * UPR;   // [BN][UPR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int ntn = N / BN;
+  const int bj = blockIdx.x >> 3;
+  const int mt = (bj / ntn) * 8 + (blockIdx.x & 7), nt = bj - (bj / ntn) * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  if (m0 >= M) return;  // the row-block count is padded to a multiple of 8 (whole workgroup, before any barrier)
   const int half = lane >> 5, l31 = lane & 31;
+  auto slot = [](int row, int unit, int plane) { return (unit ^ (row & 7)) | ((plane ^ ((row >> 3) & 1)) << 3); };
   f32x16 acc[WMT][WNT];
 #pragma unroll
   for (int i = 0; i < WMT; ++i)
@@ -807,50 +887,46 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
     for (int j = 0; j < WNT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int sfu = tid & (F4R - 1), srow = tid / F4R;  // float4 index inside the staged row (k = 4 sfu ..), rows srow + RSTEP it
+  // plane staging: thread -> (row tid >> 4 (+ 16 it), plane (tid >> 3) & 1, unit tid & 7): 8 lanes cover 128 contiguous bytes
+  const int pu = tid & 7, ppl = (tid >> 3) & 1, prow = tid >> 4;
+  // fp32 staging (AS = false): float4 index tid & 15 of row tid >> 4 (+ 16 it)
+  const int sfu = tid & 15;
   const int k0 = blockIdx.z * kstages * BKS;
-  f32x4 ra[RA], rw[WS ? 1 : RW];
-  u32x2b rwh[WS ? RW : 1], rwl[WS ? RW : 1];
+  f32x4 ra[AS ? 1 : RA];
+  u32x4b rap[AS ? RA : 1], rwp[RW];
+  const unsigned short* Wp = ppl ? Wlo : Whi;
+  const unsigned short* Ap = ppl ? Alo : Ahi;
   auto issue = [&](int st) {
 #pragma unroll
     for (int it = 0; it < RA; ++it) {
-      int m = m0 + srow + RSTEP * it;
+      int m = m0 + prow + RPP * it;
       if (m >= M) m = M - 1;
-      ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + k0 + st * BKS + sfu * 4);
+      if (AS) rap[it] = *reinterpret_cast<const u32x4b*>(Ap + (size_t)m * lda + k0 + st * BKS + pu * 8);
+      else ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + k0 + st * BKS + sfu * 4);
     }
 #pragma unroll
-    for (int it = 0; it < RW; ++it) {
-      const size_t e = (size_t)(n0 + srow + RSTEP * it) * K + k0 + st * BKS + sfu * 4;
-      if (WS) {
-        rwh[it] = *reinterpret_cast<const u32x2b*>(Whi + e);
-        rwl[it] = *reinterpret_cast<const u32x2b*>(Wlo + e);
-      } else {
-        rw[it] = *reinterpret_cast<const f32x4*>(W + e);
-      }
-    }
-  };
-  auto put_split = [&](u32x4b* base, int row, u32x2b h, u32x2b l) {
-    const int p = (sfu >> 1) ^ (row & (PPR - 1)), sub = sfu & 1;
-    unsigned char* b = reinterpret_cast<unsigned char*>(base + row * UPR);
-    *reinterpret_cast<u32x2b*>(b + p * 16 + sub * 8) = h;
-    *reinterpret_cast<u32x2b*>(b + (PPR + p) * 16 + sub * 8) = l;
-  };
-  auto put = [&](u32x4b* base, int row, const f32x4& v) {
-    const int p = (sfu >> 1) ^ (row & (PPR - 1)), sub = sfu & 1;
-    unsigned h0, l0, h1, l1;
-    split_bf16_pair(v[0], v[1], h0, l0);
-    split_bf16_pair(v[2], v[3], h1, l1);
-    unsigned char* b = reinterpret_cast<unsigned char*>(base + row * UPR);
-    *reinterpret_cast<u32x2b*>(b + p * 16 + sub * 8) = u32x2b{h0, h1};
-    *reinterpret_cast<u32x2b*>(b + (PPR + p) * 16 + sub * 8) = u32x2b{l0, l1};
+    for (int it = 0; it < RW; ++it)
+      rwp[it] = *reinterpret_cast<const u32x4b*>(Wp + (size_t)(n0 + prow + RPP * it) * K + k0 + st * BKS + pu * 8);
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int it = 0; it < RA; ++it) put(sA, srow + RSTEP * it, ra[it]);
+    for (int it = 0; it < RA; ++it) {
+      const int row = prow + RPP * it;
+      if (AS) {
+        sA[row * UPR + slot(row, pu, ppl)] = rap[it];
+      } else {
+        unsigned h0, l0, h1, l1;
+        split_bf16_pair(ra[it][0], ra[it][1], h0, l0);
+        split_bf16_pair(ra[it][2], ra[it][3], h1, l1);
+        unsigned char* b = reinterpret_cast<unsigned char*>(sA + row * UPR);
+        *reinterpret_cast<u32x2b*>(b + slot(row, sfu >> 1, 0) * 16 + (sfu & 1) * 8) = u32x2b{h0, h1};
+        *reinterpret_cast<u32x2b*>(b + slot(row, sfu >> 1, 1) * 16 + (sfu & 1) * 8) = u32x2b{l0, l1};
+      }
+    }
 #pragma unroll
     for (int it = 0; it < RW; ++it) {
-      if (WS) put_split(sW, srow + RSTEP * it, rwh[it], rwl[it]);
-      else put(sW, srow + RSTEP * it, rw[it]);
+      const int row = prow + RPP * it;
+      sW[row * UPR + slot(row, pu, ppl)] = rwp[it];
     }
   };
   C += (size_t)blockIdx.z * M * ldc;
@@ -866,17 +942,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
       for (int i = 0; i < WMT; ++i) {
         const int arow = (wm * WMT + i) * 32 + l31;
         const u32x4b* ap = sA + arow * UPR;
-        const int pa = (2 * s8 + half) ^ (arow & (PPR - 1));
-        ah[i] = __builtin_bit_cast(bf16x8, ap[pa]);
-        al[i] = __builtin_bit_cast(bf16x8, ap[PPR + pa]);
+        ah[i] = __builtin_bit_cast(bf16x8, ap[slot(arow, 2 * s8 + half, 0)]);
+        al[i] = __builtin_bit_cast(bf16x8, ap[slot(arow, 2 * s8 + half, 1)]);
       }
 #pragma unroll
       for (int j = 0; j < WNT; ++j) {
         const int wrow = (wn * WNT + j) * 32 + l31;
         const u32x4b* wp = sW + wrow * UPR;
-        const int pw = (2 * s8 + half) ^ (wrow & (PPR - 1));
-        wh[j] = __builtin_bit_cast(bf16x8, wp[pw]);
-        wl[j] = __builtin_bit_cast(bf16x8, wp[PPR + pw]);
+        wh[j] = __builtin_bit_cast(bf16x8, wp[slot(wrow, 2 * s8 + half, 0)]);
+        wl[j] = __builtin_bit_cast(bf16x8, wp[slot(wrow, 2 * s8 + half, 1)]);
       }
 #pragma unroll
       for (int i = 0; i < WMT; ++i)
@@ -901,7 +975,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
         if (m < M) {
           float v = acc[i][j][r] + bv;
           if (EPI == 1) v = gelu_erf(v);
-          C[(size_t)m * ldc + n] = v;
+          if (Chi) {
+            // lanes n, n + 1 trade one term (quad_perm [1,0,3,2]): the even lane stores the pair of hi terms, the odd
+            // lane the pair of lo terms - one 4-byte store per lane, 128 contiguous bytes per 32 lanes, as on the fp32 side
+            unsigned short h, l;
+            split_bf16_one(v, h, l);
+            const bool odd = lane & 1;
+            const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h : l), 0xB1, 0xF, 0xF, true);
+            const unsigned word = odd ? (got | ((unsigned)l << 16)) : ((unsigned)h | (got << 16));
+            *reinterpret_cast<unsigned*>((odd ? Clo : Chi) + (size_t)m * ldc + (n & ~1)) = word;
+          } else {
+            C[(size_t)m * ldc + n] = v;
+          }
         }
       }
   }
@@ -910,11 +995,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf_s(const float* __restrict__ 
 constexpr int kMaxSplit = 4;
 
 void launch_add_ln(const float* a, int nsplit, const float* abias, const float* r, int T, int H, const float* g,
-                   const float* b, float eps, float* out, hipStream_t stream) {
+                   const float* b, float eps, float* out, hipStream_t stream, unsigned short* ohi = nullptr,
+                   unsigned short* olo = nullptr) {
   const dim3 grid((unsigned)(((size_t)T * 64 + 255) / 256)), block(256);
-  if (H == 384) hipLaunchKernelGGL(k_add_ln_fixed<6>, grid, block, 0, stream, a, nsplit, abias, r, T, g, b, eps, out);
-  else if (H == 768) hipLaunchKernelGGL(k_add_ln_fixed<12>, grid, block, 0, stream, a, nsplit, abias, r, T, g, b, eps, out);
-  else hipLaunchKernelGGL(k_add_ln, grid, block, 0, stream, a, nsplit, abias, r, T, H, g, b, eps, out);
+  if (H == 384) hipLaunchKernelGGL(k_add_ln_fixed<6>, grid, block, 0, stream, a, nsplit, abias, r, T, g, b, eps, out, ohi, olo);
+  else if (H == 768) hipLaunchKernelGGL(k_add_ln_fixed<12>, grid, block, 0, stream, a, nsplit, abias, r, T, g, b, eps, out, ohi, olo);
+  else hipLaunchKernelGGL(k_add_ln, grid, block, 0, stream, a, nsplit, abias, r, T, H, g, b, eps, out, ohi, olo);
 }
 
 // Split-K factor for the two GEMMs that feed k_add_ln (N = hidden): with M = a few hundred tokens a 64x64 tiling
@@ -935,23 +1021,78 @@ int pick_splits(int M, int N, int K) {
   return s;
 }
 
+struct Planes {  // an activation tensor as its two bf16 terms, [rows][ld] each
+  unsigned short* hi = nullptr;
+  unsigned short* lo = nullptr;
+};
+
+bool env_on(const char* name) { return !(getenv(name) && atoi(getenv(name)) == 0); }
+
+// true when gemm() runs this shape on k_gemm_bf_s with pre-split weights: the kernels that take / write planes
+bool gemm_takes_planes(int K, int splits) {
+  static const bool on = env_on("EIOKU_GEMM_BF16") && env_on("EIOKU_GEMM_S");
+  return on && K % (128 * splits) == 0;
+}
+
+template <int EPI, int WMT, int WNT, bool AS, int WGM = 2>
+void launch_bf64(dim3 grid, size_t lds, hipStream_t stream, const float* A, int lda, const float* W, const unsigned short* whi,
+                 const unsigned short* wlo, const float* bias, float* C, int ldc, int M, int N, int K, int kst, const Planes* ap,
+                 const Planes* cp) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<EPI, WMT, WNT, AS, WGM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_gemm_bf_s<EPI, WMT, WNT, AS, WGM>), grid, dim3(128 * WGM), lds, stream, A, lda, whi, wlo, bias, C, ldc, M, N, K, kst,
+                     ap ? ap->hi : nullptr, ap ? ap->lo : nullptr, cp ? cp->hi : nullptr, cp ? cp->lo : nullptr);
+}
+
 // C = A . W^T (+ bias, + GELU when epi == 1).  splits > 1: C receives `splits` partial planes [splits][M][ldc]
-// WITHOUT bias (epi must be 0); the consumer adds them up.
+// WITHOUT bias (epi must be 0); the consumer adds them up.  `ap` / `cp` (only where gemm_takes_planes()): A is read
+// from / C is written as bf16 hi + lo planes (A / C themselves are then not touched).
 int gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int epi,
-         int splits, hipStream_t stream, const eioku_bert::SplitW* ws = nullptr) {
+         int splits, hipStream_t stream, const eioku_bert::SplitW* ws = nullptr, const Planes* ap = nullptr,
+         const Planes* cp = nullptr) {
   EIOKU_REQUIRE(N % 128 == 0 && K % kBK == 0, "gemm shape N=%d K=%d must be multiples of 128 / 32", N, K);
   EIOKU_REQUIRE(splits >= 1 && (K / kBK) % splits == 0 && (splits == 1 || epi == 0), "bad split-K %d", splits);
   const int kchunks = K / kBK / splits;
   if (splits > 1) bias = nullptr;
+  const bool s_route = K % (128 * splits) == 0 && env_on("EIOKU_GEMM_S");
+  const bool bf = env_on("EIOKU_GEMM_BF16");
+  const unsigned short* whi = ws ? ws->hi : nullptr;
+  const unsigned short* wlo = ws ? ws->lo : nullptr;
+  EIOKU_REQUIRE(!(ap || cp) || (s_route && bf && whi && (!cp || splits == 1)), "planes on a GEMM route that has none");
   prof_start(EIOKU_PROF_GEMM, stream);
   // EIOKU_GEMM_BF16=0 / EIOKU_GEMM_S=0 / EIOKU_ATTN_MFMA=0 route the encoder through the fp32-FMA kernels (the
   // numerics cross-check of tests/test_bert_gpu.py::test_fp32_fma_route_matches_the_mfma_route)
-  static const bool bf_all = !(getenv("EIOKU_GEMM_BF16") && atoi(getenv("EIOKU_GEMM_BF16")) == 0);
-  if (M >= 8192 && !(bf_all && K % (128 * splits) == 0)) {
+  if (s_route && bf && whi) {
+    const int kst = K / 64 / splits;  // 64-deep stages
+    if (M >= 8192 && splits == 1) {
+      // 128 x 128 tiles (64 KB of LDS, two workgroups per CU)
+      const dim3 grid((unsigned)(((M + 127) / 128 + 7) / 8 * 8 * (N / 128)), 1u, 1u);  // row blocks padded to the 8 XCDs
+      const size_t lds = (size_t)(128 + 128) * 64 * 4;
+#define EIOKU_L(E, AS_) launch_bf64<E, 2, 2, AS_>(grid, lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kst, ap, cp)
+      if (epi == 1) { if (ap) EIOKU_L(1, true); else EIOKU_L(1, false); }
+      else { if (ap) EIOKU_L(0, true); else EIOKU_L(0, false); }
+#undef EIOKU_L
+    } else {
+      // small M (the ingest path: a few segments per call, running beside the detector): 64 x 64 tiles, 32 KB of LDS
+      // per workgroup.  64-deep stages are as fast alone as 128-deep ones (0.457 vs 0.460 ms per 8 x 128 tokens) but
+      // two workgroups no longer take 128 of a CU's 160 KB away from the conv kernels on the other streams: +1.5 % on
+      // the overlapped step.  Same k order, so the results are bit-identical.
+      const dim3 grid((unsigned)(((M + 63) / 64 + 7) / 8 * 8 * (N / 64)), 1u, (unsigned)splits);
+      const size_t lds = (size_t)(64 + 64) * 64 * 4;
+#define EIOKU_L(E, AS_) launch_bf64<E, 1, 1, AS_>(grid, lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kst, ap, cp)
+      if (epi == 1) { if (ap) EIOKU_L(1, true); else EIOKU_L(1, false); }
+      else { if (ap) EIOKU_L(0, true); else EIOKU_L(0, false); }
+#undef EIOKU_L
+    }
+  } else if (M >= 8192 && !(bf && s_route)) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)(N / 128), (unsigned)splits);
     if (epi == 1) hipLaunchKernelGGL((k_gemm_f32<1, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
     else hipLaunchKernelGGL((k_gemm_f32<0, 128, 128>), grid, dim3(256), 0, stream, A, lda, W, bias, C, ldc, M, N, K, kchunks);
-  } else if (K % (128 * splits) == 0 && !(getenv("EIOKU_GEMM_S") && atoi(getenv("EIOKU_GEMM_S")) == 0)) {
+  } else if (s_route) {
     dim3 grid((unsigned)((M + 63) / 64), (unsigned)(N / 64), (unsigned)splits);
     const size_t lds = (size_t)(64 + 64) * 128 * 4;
     static bool attr = false;
@@ -960,41 +1101,9 @@ int gemm(const float* A, int lda, const float* W, const float* bias, float* C, i
       EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f32_s<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr = true;
     }
-    // small M (the ingest path: a few segments per call, running beside the detector): 64-deep stages = 32 KB of LDS
-    // per workgroup instead of 64.  The GEMM alone is as fast (0.457 vs 0.460 ms per 8 x 128 tokens) but two of its
-    // workgroups no longer take 128 of a CU's 160 KB away from the conv kernels on the other streams: +1.5 % on the
-    // overlapped step.  Same k order, so the results are bit-identical.
-    const bool bks64 = M < 8192;
     const int kstages = K / 128 / splits;
-    static const bool bf = !(getenv("EIOKU_GEMM_BF16") && atoi(getenv("EIOKU_GEMM_BF16")) == 0);
-    static bool attr2 = false;
-    if (bf && !attr2) {
-      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr2 = true;
-    }
-    const unsigned short* whi = ws ? ws->hi : nullptr;
-    const unsigned short* wlo = ws ? ws->lo : nullptr;
-    if (bf && whi && M >= 8192 && N % 128 == 0 && splits == 1) {
-      // 128 x 128 tiles, 64-deep stages (64 KB of LDS, two workgroups per CU)
-      static bool attr3 = false;
-      if (!attr3) {
-        EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<0, true, 64, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf_s<1, true, 64, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr3 = true;
-      }
-      dim3 grid2((unsigned)((M + 127) / 128), (unsigned)(N / 128), 1u);
-      if (epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, true, 64, 2, 2>), grid2, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages * 2);
-      else hipLaunchKernelGGL((k_gemm_bf_s<0, true, 64, 2, 2>), grid2, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages * 2);
-    } else if (bf && whi && bks64 && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, true, 64>), grid, dim3(256), lds / 2, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages * 2);
-    else if (bf && whi && bks64) hipLaunchKernelGGL((k_gemm_bf_s<0, true, 64>), grid, dim3(256), lds / 2, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages * 2);
-    else if (bf && whi && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, true>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
-    else if (bf && whi) hipLaunchKernelGGL((k_gemm_bf_s<0, true>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
-    else if (bf && epi == 1) hipLaunchKernelGGL((k_gemm_bf_s<1, false>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
-    else if (bf) hipLaunchKernelGGL((k_gemm_bf_s<0, false>), grid, dim3(256), lds, stream, A, lda, W, whi, wlo, bias, C, ldc, M, N, K, kstages);
-    else if (epi == 1) hipLaunchKernelGGL((k_gemm_f32_s<1>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
+    // EIOKU_GEMM_BF16=0, or a caller without the handle's weight planes: the exact-fp32 matrix pipe
+    if (epi == 1) hipLaunchKernelGGL((k_gemm_f32_s<1>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
     else hipLaunchKernelGGL((k_gemm_f32_s<0>), grid, dim3(256), lds, stream, A, lda, W, bias, C, ldc, M, N, K, kstages);
   } else {
     dim3 grid((unsigned)((M + 63) / 64), (unsigned)(N / 64), (unsigned)splits);
@@ -1091,7 +1200,7 @@ void eioku_bert_destroy(eioku_bert* m) {
     if (w.hi) (void)hipFree(w.hi);
     if (w.lo) (void)hipFree(w.lo);
   }
-  void* bufs[] = {m->d_ids, m->d_mask, m->x, m->y, m->qkv, m->ctx, m->mid, m->d_out};
+  void* bufs[] = {m->d_ids, m->d_mask, m->x, m->y, m->qkv, m->ctx, m->mid, m->d_out, m->xp, m->cp, m->mp};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete m;
@@ -1167,17 +1276,34 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
     d_mask = m->d_mask;
     d_out = m->d_out;
   }
+  // every GEMM of a layer on the split-bf16 kernels (the default): each activation a GEMM reads is written by its
+  // producer as bf16 hi | lo planes; ctx and the FFN's 4H-wide intermediate then exist only in that form
+  const int sp_o = pick_splits(T, H, H), sp_f = pick_splits(T, H, m->ffn);
+  const bool planes = gemm_takes_planes(H, 1) && gemm_takes_planes(H, sp_o) && gemm_takes_planes(m->ffn, sp_f);
   if ((rc = grow(&m->x, &m->x_cap, (size_t)T * H * 4))) return rc;
   if ((rc = grow(&m->y, &m->y_cap, (size_t)kMaxSplit * T * H * 4))) return rc;
-  if ((rc = grow(&m->ctx, &m->ctx_cap, (size_t)T * H * 4))) return rc;
   if ((rc = grow(&m->qkv, &m->qkv_cap, (size_t)T * 3 * H * 4))) return rc;
-  if ((rc = grow(&m->mid, &m->mid_cap, (size_t)T * m->ffn * 4))) return rc;
+  Planes xP, cP, mP;
+  if (planes) {
+    if ((rc = grow(&m->xp, &m->xp_cap, (size_t)2 * T * H * 2))) return rc;
+    if ((rc = grow(&m->cp, &m->cp_cap, (size_t)2 * T * H * 2))) return rc;
+    if ((rc = grow(&m->mp, &m->mp_cap, (size_t)2 * T * m->ffn * 2))) return rc;
+    xP.hi = m->xp; xP.lo = m->xp + (size_t)T * H;
+    cP.hi = m->cp; cP.lo = m->cp + (size_t)T * H;
+    mP.hi = m->mp; mP.lo = m->mp + (size_t)T * m->ffn;
+  } else {
+    if ((rc = grow(&m->mid, &m->mid_cap, (size_t)T * m->ffn * 4))) return rc;
+  }
+  const bool amfma = env_on("EIOKU_ATTN_MFMA") && S <= 128 && H == m->heads * 32;
+  // the other attention kernels write fp32 ctx (split afterwards by k_split_planes when the GEMMs take planes)
+  if (!planes || !amfma)
+    if ((rc = grow(&m->ctx, &m->ctx_cap, (size_t)T * H * 4))) return rc;
 
   const unsigned tok_blocks = (unsigned)(((size_t)T * 64 + 255) / 256);
   hipLaunchKernelGGL(k_embed_ln, dim3(tok_blocks), dim3(256), 0, stream, d_ids, T, S, H, m->vocab,
                      tp(m, "embeddings.word_embeddings.weight"), tp(m, "embeddings.position_embeddings.weight"),
                      tp(m, "embeddings.token_type_embeddings.weight"), tp(m, "embeddings.LayerNorm.weight"),
-                     tp(m, "embeddings.LayerNorm.bias"), m->eps, m->x);
+                     tp(m, "embeddings.LayerNorm.bias"), m->eps, m->x, xP.hi, xP.lo);
   EIOKU_LAUNCH_CHECK();
   const int parts = S <= 256 ? 4 : 1;
   const int qsplit = parts == 4 ? (S + 31) / 32 : 1;  // 32 queries x 4 lanes = 2 waves per workgroup
@@ -1191,31 +1317,42 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
       attr = true;
     }
   }
+  const Planes* xa = planes ? &xP : nullptr;
+  const Planes* ca = planes ? &cP : nullptr;
+  const Planes* ma = planes ? &mP : nullptr;
   for (int l = 0; l < m->L; ++l) {
     const std::string p = "encoder.layer." + std::to_string(l) + ".";
     if ((rc = gemm(m->x, H, tp(m, p + "attention.self.query.weight"), tp(m, p + "attention.self.query.bias"), m->qkv,
-                   3 * H, T, 3 * H, H, 0, 1, stream, &m->wsplit[(size_t)4 * l + 0]))) return rc;
-    static const bool amfma = !(getenv("EIOKU_ATTN_MFMA") && atoi(getenv("EIOKU_ATTN_MFMA")) == 0);
-    if (amfma && S <= 128 && H == m->heads * 32)
-      hipLaunchKernelGGL(k_attention_mfma, dim3(B, m->heads), dim3(256), 0, stream, m->qkv, d_mask, S, H, m->ctx);
-    else if (parts == 4)
-      hipLaunchKernelGGL(k_attention8, dim3(B, m->heads, qsplit), dim3(256), alds, stream, m->qkv, d_mask, S, H, m->ctx);
-    else
-      hipLaunchKernelGGL(k_attention<1>, dim3(B, m->heads), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
+                   3 * H, T, 3 * H, H, 0, 1, stream, &m->wsplit[(size_t)4 * l + 0], xa))) return rc;
+    if (amfma) {
+      hipLaunchKernelGGL(k_attention_mfma, dim3(B, m->heads), dim3(256), 0, stream, m->qkv, d_mask, S, H, m->ctx, cP.hi, cP.lo);
+    } else {
+      if (parts == 4)
+        hipLaunchKernelGGL(k_attention8, dim3(B, m->heads, qsplit), dim3(256), alds, stream, m->qkv, d_mask, S, H, m->ctx);
+      else
+        hipLaunchKernelGGL(k_attention<1>, dim3(B, m->heads), dim3(athreads), alds, stream, m->qkv, d_mask, S, H, m->ctx);
+      if (planes) {
+        const size_t npairs = (size_t)T * H / 2;
+        hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, stream, m->ctx, npairs,
+                           (unsigned*)cP.hi, (unsigned*)cP.lo);
+      }
+    }
     EIOKU_LAUNCH_CHECK();
-    const int sp_o = pick_splits(T, H, H), sp_f = pick_splits(T, H, m->ffn);
     if ((rc = gemm(m->ctx, H, tp(m, p + "attention.output.dense.weight"), tp(m, p + "attention.output.dense.bias"), m->y,
-                   H, T, H, H, 0, sp_o, stream, &m->wsplit[(size_t)4 * l + 1]))) return rc;
+                   H, T, H, H, 0, sp_o, stream, &m->wsplit[(size_t)4 * l + 1], ca))) return rc;
     launch_add_ln(m->y, sp_o, sp_o > 1 ? tp(m, p + "attention.output.dense.bias") : nullptr, m->x, T, H,
                        tp(m, p + "attention.output.LayerNorm.weight"), tp(m, p + "attention.output.LayerNorm.bias"),
-                       m->eps, m->x, stream);
+                       m->eps, m->x, stream, xP.hi, xP.lo);
     EIOKU_LAUNCH_CHECK();
     if ((rc = gemm(m->x, H, tp(m, p + "intermediate.dense.weight"), tp(m, p + "intermediate.dense.bias"), m->mid, m->ffn,
-                   T, m->ffn, H, 1, 1, stream, &m->wsplit[(size_t)4 * l + 2]))) return rc;
+                   T, m->ffn, H, 1, 1, stream, &m->wsplit[(size_t)4 * l + 2], xa, ma))) return rc;
     if ((rc = gemm(m->mid, m->ffn, tp(m, p + "output.dense.weight"), tp(m, p + "output.dense.bias"), m->y, H, T, H,
-                   m->ffn, 0, sp_f, stream, &m->wsplit[(size_t)4 * l + 3]))) return rc;
+                   m->ffn, 0, sp_f, stream, &m->wsplit[(size_t)4 * l + 3], ma))) return rc;
+    // the last layer's output feeds the pooling only: no planes
+    const bool last = l + 1 == m->L;
     launch_add_ln(m->y, sp_f, sp_f > 1 ? tp(m, p + "output.dense.bias") : nullptr, m->x, T, H,
-                       tp(m, p + "output.LayerNorm.weight"), tp(m, p + "output.LayerNorm.bias"), m->eps, m->x, stream);
+                       tp(m, p + "output.LayerNorm.weight"), tp(m, p + "output.LayerNorm.bias"), m->eps, m->x, stream,
+                       last ? nullptr : xP.hi, last ? nullptr : xP.lo);
     EIOKU_LAUNCH_CHECK();
   }
   const int pthreads = ((H + 63) / 64) * 64;
