@@ -104,7 +104,17 @@ struct ConvArgs {
   int in2_cs, c_split;
   // tensor extents, read by the bounds-check build only
   BcExt x_in, x_in2, x_res, x_out, x_img, x_cls;
+  // 1: the persistent kernels walk their tiles in XCD-contiguous order (xcd_tile below)
+  int xcd_tiles;
 };
+
+// Workgroups b, b + 8, b + 16 ... share an XCD and its L2.  A persistent kernel that takes tiles b, b + G, b + 2G ...
+// has every tile's spatial neighbours (the halo rows and columns it re-reads: 40 % of an 8 x 16 tile's patch) on other
+// XCDs.  With this order XCD x owns the contiguous tiles [x T / 8, (x + 1) T / 8) and its workgroups walk them side by
+// side, so halos are L2 hits.  Identity when T is not a multiple of 8 (odd batch sizes).
+__device__ __forceinline__ int xcd_tile(int v, int total, int on) {
+  return (on && (total & 7) == 0) ? (v & 7) * (total >> 3) + (v >> 3) : v;
+}
 
 // x / d for 0 <= x < 2^24 (exact int->float) with a precomputed 1.0f/d: one multiply and a +-1 fix-up instead
 // of the ~40-instruction integer division (the flattened kernel does ~20 of them before its first load)
@@ -718,6 +728,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv3x3_persist(ConvArgs a, int to
   unsigned s_ok = 0;  // bit j: slot j of the staged tile holds fetched data (else zero padding)
   int nx_n = 0, nx_th = 0, nx_tw = 0;  // coordinates of the staged tile
   auto issue = [&](int tile) {
+    tile = xcd_tile(tile, total_tiles, a.xcd_tiles);
     nx_n = fast_div(tile, tiles_per_img, r_tpi);
     const int t2 = tile - nx_n * tiles_per_img;
     nx_th = fast_div(t2, a.tiles_w, r_tw);
@@ -962,6 +973,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, 
   unsigned s_ok = 0;
   int nx_n = 0, nx_th = 0, nx_tw = 0;
   auto issue = [&](int tile) {
+    tile = xcd_tile(tile, total_tiles, a.xcd_tiles);
     nx_n = fast_div(tile, tiles_per_img, r_tpi);
     const int t2 = tile - nx_n * tiles_per_img;
     nx_th = fast_div(t2, a.tiles_w, r_tw);
@@ -1265,7 +1277,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_pair_rs(ConvArgs a, int rows
   const int tiles_per_img = a.tiles_w * a.tiles_h;
   const float r_tpi = 1.0f / (float)tiles_per_img, r_tw = 1.0f / (float)a.tiles_w;
   constexpr int NLOAD = kRS_XH * kRS_XW * 8, R = (NLOAD + 255) / 256;  // 16-byte units of the input patch (64 channels)
-  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+  for (int vt = blockIdx.x; vt < total_tiles; vt += gridDim.x) {
+    const int tile = xcd_tile(vt, total_tiles, a.xcd_tiles);
     const int tn = fast_div(tile, tiles_per_img, r_tpi);
     const int t2 = tile - tn * tiles_per_img;
     const int tth = fast_div(t2, a.tiles_w, r_tw), ttw = t2 - tth * a.tiles_w;
@@ -1411,6 +1424,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
   unsigned s_in = 0, s_img = 0;  // bit j: slot inside the network input / inside the image (fused modes)
   int nx_n = 0, nx_th = 0, nx_tw = 0;
   auto issue = [&](int tile) {
+    tile = xcd_tile(tile, total_tiles, a.xcd_tiles);
     nx_n = fast_div(tile, tiles_per_img, r_tpi);
     const int t2 = tile - nx_n * tiles_per_img;
     nx_th = fast_div(t2, a.tiles_w, r_tw);
@@ -1639,6 +1653,7 @@ __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st
   bool s_full = false;
   int nx_n = 0, nx_th = 0, nx_tw = 0;
   auto issue = [&](int tile) {
+    tile = xcd_tile(tile, total_tiles, a.xcd_tiles);
     nx_n = fast_div(tile, tiles_per_img, r_tpi);
     const int t2 = tile - nx_n * tiles_per_img;
     nx_th = fast_div(t2, a.tiles_w, r_tw);
@@ -2256,6 +2271,12 @@ bool conv_clsmax_ok(const ConvWeights& cw, int act) {
   return !off && cw.ks == 1 && cw.ntiles == 1 && act == kActNone;
 }
 
+// EIOKU_XCD_TILES=0: the r2 tile order (b, b + G, ...), for A/B runs and the byte-identity test of the two orders
+static int xcd_tiles_on() {
+  static const int on = !(getenv("EIOKU_XCD_TILES") && atoi(getenv("EIOKU_XCD_TILES")) == 0);
+  return on;
+}
+
 bool conv_post_ok(const ConvWeights& cw, const ConvWeights& post) {
   static const bool off = getenv("EIOKU_CONV_POST") && atoi(getenv("EIOKU_CONV_POST")) == 0;
   if (off) return false;
@@ -2338,6 +2359,7 @@ int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, i
   if (N == 0) return EIOKU_OK;
   EIOKU_REQUIRE((long long)N * H * W * in.cstride < (1ll << 31), "tensor exceeds 32-bit element offsets -- split the batch");
   ConvArgs a{};
+  a.xcd_tiles = xcd_tiles_on();
   a.in = in.ptr + in.coff;
   a.wgt = reinterpret_cast<const uint4*>(ca.d_w);
   a.bias = ca.d_b;
@@ -2424,6 +2446,7 @@ int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, cons
   EIOKU_REQUIRE(out.ptr && out.cstride % 4 == 0 && out.coff % 4 == 0, "bad output slice");
   if (N == 0) return EIOKU_OK;
   ConvArgs a{};
+  a.xcd_tiles = xcd_tiles_on();
   a.wgt = reinterpret_cast<const uint4*>(c1.d_w);
   a.bias = c1.d_b;
   a.N = N;
@@ -2501,6 +2524,7 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
                   "tensor of %lld pixels exceeds the kernels' 32-bit element offsets -- split the batch", px_in);
   }
   ConvArgs a;
+  a.xcd_tiles = xcd_tiles_on();
   a.in = in.ptr ? in.ptr + in.coff : nullptr;
   a.wgt = reinterpret_cast<const uint4*>(cw.d_w);
   a.bias = cw.d_b;

@@ -301,8 +301,8 @@ def test_detect_fusion_switches_leave_the_detections_byte_identical(gpu, tmp_pat
     """Every detect()-level fusion the library keeps a switch for (each read once per process): the one-launch
     YOLOv8n front end (EIOKU_STEM_CHAIN), the stem reading the BGR frames itself (EIOKU_STEM_FUSE), the class head
     writing {max logit, argmax} words instead of 80 logits (EIOKU_CLSMAX) and the lazily evaluated box branch
-    (EIOKU_LAZY_BOX).  640-wide copy-mode sources so that all of them are eligible; the detections of every
-    variant must be the all-on bytes."""
+    (EIOKU_LAZY_BOX), plus the XCD-contiguous tile order of the persistent conv kernels (EIOKU_XCD_TILES, r3).  640-wide
+    copy-mode sources so that all of them are eligible; the detections of every variant must be the all-on bytes."""
     import os
     import subprocess
     import sys
@@ -323,7 +323,7 @@ def test_detect_fusion_switches_leave_the_detections_byte_identical(gpu, tmp_pat
         "np.savez(sys.argv[1], *out)\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     outs = {}
-    for name in ("all_on", "EIOKU_STEM_CHAIN", "EIOKU_STEM_FUSE", "EIOKU_CLSMAX", "EIOKU_LAZY_BOX"):
+    for name in ("all_on", "EIOKU_STEM_CHAIN", "EIOKU_STEM_FUSE", "EIOKU_CLSMAX", "EIOKU_LAZY_BOX", "EIOKU_XCD_TILES"):
         path = tmp_path / f"dets_{name}.npz"
         env = dict(os.environ) if name == "all_on" else dict(os.environ, **{name: "0"})
         subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=env, timeout=300)
