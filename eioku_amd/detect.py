@@ -259,7 +259,7 @@ class PipelinedDetector:
     batch i+1 overlaps the kernels of batch i; the frame loop of ``ModelManager`` and ``bench.py`` both run on it.
     """
 
-    def __init__(self, first: Yolov8Detector, depth: int = 2, device=None):
+    def __init__(self, first: Yolov8Detector, depth: int = 2, device=None, streams=None):
         import torch
 
         if depth < 1:
@@ -274,7 +274,13 @@ class PipelinedDetector:
         # high priority: the detector's persistent kernels size their grids for the whole chip; workgroups of other
         # streams' kernels (scene, embed) that sit on a CU when such a grid arrives turn into a straggler round
         # (measured on the overlapped bench step: 1.505 -> 1.46 ms)
-        self._streams = [torch.cuda.Stream(device=self._device, priority=-1) for _ in self._handles]
+        # `streams`: lanes handed in by a caller that builds one pipeline after another (a stream's hardware queue is
+        # fixed when it is created; the lanes of a later pipeline can land on queues that make them share one with the
+        # caller's other streams: bench.py's cfg4 runs measured 41 k instead of 58 k frames/s after the earlier runs)
+        self._streams = list(streams) if streams is not None else [
+            torch.cuda.Stream(device=self._device, priority=-1) for _ in self._handles]
+        if len(self._streams) != len(self._handles):
+            raise ValueError("one stream per handle")
         self._pending = []  # (dets, counts, event, frames kept alive)
         self._n = 0
 
