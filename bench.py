@@ -560,6 +560,9 @@ def main():
     # launches per step are themselves ~15% of a step and because overlapped stages stretch each other's kernels
     def profiled(i, args=args):
         if args.prof_every < 0:
+            # the middle step.  (Profiling the FIRST timed step instead - the pipeline is empty there anyway, so no second
+            # drain / refill - gains 1-2 % on `value` at 20 steps but measures the kernels right behind the idle barrier:
+            # roofline.frac 0.117 instead of 0.124 on the same box; the kernel figure is the one to keep honest.)
             return i == args.steps // 2
         return args.prof_every > 0 and i % args.prof_every == 0
 
@@ -622,7 +625,7 @@ def main():
                        "batch": args.batch, "frame": [height, width], "parallelism": f"shard-by-video x{world}"},
             "roofline": {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": achieved, "peak": dom["peak"],
                          "unit": dom["unit"], "frac": achieved / dom["peak"], "traffic": traffic, "traffic_note": tnote,
-                         "traffic_per_launch": (traffic / dom["launches"] * max(pipe.prof_steps, 1)) if traffic else None,
+                         "traffic_per_launch": (traffic / dom["launches"] * max(pipe.prof_steps, 1)) if traffic and dom["launches"] else None,
                          "avg_kernel_ms": avg_ms, "launches": dom["launches"],
                          "kernel_ms_per_step": dom["ms_total"] / max(pipe.prof_steps, 1), "profiled_steps": pipe.prof_steps,
                          "algorithmic_per_step": dom["alg_per_step"], "scene_kernels": pipe.scene_kernels()},
