@@ -262,6 +262,40 @@ def test_list_major_scan_is_bit_identical_to_query_major(gpu, d, m, nlist, n, nq
     ix._quantizer.close()
 
 
+def test_list_major_results_do_not_depend_on_its_launch_knobs(gpu, tmp_path):
+    """EIOKU_LSCAN_NW (waves per workgroup) and EIOKU_LSCAN_TAU_ROWS (rows of the bound pass) are read once per process:
+    each value in its own process, same index, same queries - distances and ids must be the default's bytes."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from eioku_amd import ivfpq\n"
+        "from oracle import prng\n"
+        "rng = np.random.default_rng(5)\n"
+        "c = rng.standard_normal((40, 128)).astype(np.float32)\n"
+        "x = (c[rng.integers(0, 40, 40000)] + 0.2 * rng.standard_normal((40000, 128))).astype(np.float32)\n"
+        "ix = ivfpq.IndexIVFPQ(128, 64, 16)\n"
+        "ix.train(x[:6000]); ix.add(x); ix.nprobe = 8\n"
+        "q = x[rng.integers(0, 40000, 150)] + 0.05 * rng.standard_normal((150, 128)).astype(np.float32)\n"
+        "D, I = ix.search(q.astype(np.float32), 10)\n"
+        "assert int(ix.last_stats[0]) == 0\n"
+        "np.savez(sys.argv[1], D=D.cpu().numpy(), I=I.cpu().numpy())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    outs = {}
+    for name, env in {"default": {}, "nw4": {"EIOKU_LSCAN_NW": "4"}, "tau128": {"EIOKU_LSCAN_TAU_ROWS": "128"},
+                      "tau8192": {"EIOKU_LSCAN_TAU_ROWS": "8192"}}.items():
+        path = tmp_path / f"{name}.npz"
+        subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=dict(os.environ, **env), timeout=300)
+        with np.load(path) as z:
+            outs[name] = (z["D"], z["I"])
+    assert (outs["default"][1] >= 0).all()
+    for name, (D, I) in outs.items():
+        assert np.array_equal(I, outs["default"][1]) and np.array_equal(D, outs["default"][0]), name
+
+
 def test_list_major_overflow_falls_back_to_the_query_major_scan(gpu):
     """A candidate capacity of 8 per query (and per workgroup list) cannot hold the survivors: the overflow flag must be
     raised and the gated query-major launches must deliver the same (D, I)."""
