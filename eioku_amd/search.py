@@ -199,14 +199,14 @@ class ShardedFlatL2:
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return D, I
         world = dist.get_world_size(self.group)
-        # one collective: pack (D, I) into a single int64 payload so a single all-gather carries both
-        payload = torch.cat([D.contiguous().view(torch.int32).to(torch.int64), I], dim=1).contiguous()
+        # one collective of 12 bytes per (distance, id): an int32 payload [nq][3k] = the float bits | the id's two halves
+        payload = torch.cat([D.contiguous().view(torch.int32), I.contiguous().view(torch.int32)], dim=1).contiguous()
         nq = payload.shape[0]
-        flat = torch.empty((world * nq, 2 * k), dtype=torch.int64, device=payload.device)
+        flat = torch.empty((world * nq, 3 * k), dtype=torch.int32, device=payload.device)
         dist.all_gather_into_tensor(flat, payload, group=self.group)  # rank-major concatenation
-        gathered = flat.view(world, nq, 2 * k)
-        dl = gathered[:, :, :k].to(torch.int32).view(torch.float32).contiguous()
-        il = gathered[:, :, k:].contiguous()
+        gathered = flat.view(world, nq, 3 * k)
+        dl = gathered[:, :, :k].contiguous().view(torch.float32)
+        il = gathered[:, :, k:].contiguous().view(torch.int64)
         return self.merge(dl, il, k)
 
 
