@@ -14,6 +14,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 #include <cmath>
 #include <string>
@@ -937,6 +938,8 @@ __global__ __launch_bounds__(128 * WGM, WGM == 2 ? 2 : 1) void k_gemm_bf_s(const
     if (st + 1 < kstages) issue(st + 1);
 #pragma unroll
     for (int s8 = 0; s8 < BKS / 16; ++s8) {
+      // (r3: reading group s8 + 1's fragments ahead of group s8's MFMAs, pinned with sched_group_barrier, measured
+      // slower - 7.44 vs 7.21 ms per 512 x 128 batch: the allocator keeps one register set and waits behind each read)
       bf16x8 ah[WMT], al[WMT], wh[WNT], wl[WNT];
 #pragma unroll
       for (int i = 0; i < WMT; ++i) {
@@ -963,19 +966,30 @@ __global__ __launch_bounds__(128 * WGM, WGM == 2 ? 2 : 1) void k_gemm_bf_s(const
     }
     __syncthreads();
   }
+  // Epilogue.  The bias values are loaded first and waited for ONCE; the store loops below are branch-free on full
+  // tiles (rows past M exist only in the last row block) and the fp32 / planes choice is made outside them.  With
+  // `if (m < M)` and `if (Chi)` around every store the compiler could not count the stores in flight behind the bias
+  // load and put an s_waitcnt vmcnt(0) in front of every value: 64 store round trips per lane, one after the other -
+  // the longest phase of the FFN1 GEMM (r3 ISA reading; profiles/r03_gemm_ablation.txt "neither": 255 us).
+  float bvs[WNT];
 #pragma unroll
-  for (int j = 0; j < WNT; ++j) {
-    const int n = n0 + (wn * WNT + j) * 32 + l31;
-    const float bv = bias ? bias[n] : 0.f;
+  for (int j = 0; j < WNT; ++j) bvs[j] = bias ? bias[n0 + (wn * WNT + j) * 32 + l31] : 0.f;
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  __builtin_amdgcn_sched_barrier(0);
+  auto store_tile = [&](auto guard_tag, auto planes_tag) {
+    constexpr bool GUARD = decltype(guard_tag)::value, PLANES = decltype(planes_tag)::value;
 #pragma unroll
-    for (int i = 0; i < WMT; ++i)
+    for (int j = 0; j < WNT; ++j) {
+      const int n = n0 + (wn * WNT + j) * 32 + l31;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * WMT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < M) {
-          float v = acc[i][j][r] + bv;
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * WMT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (GUARD && m >= M) continue;
+          float v = acc[i][j][r] + bvs[j];
           if (EPI == 1) v = gelu_erf(v);
-          if (Chi) {
+          if (PLANES) {
             // lanes n, n + 1 trade one term (quad_perm [1,0,3,2]): the even lane stores the pair of hi terms, the odd
             // lane the pair of lo terms - one 4-byte store per lane, 128 contiguous bytes per 32 lanes, as on the fp32 side
             unsigned short h, l;
@@ -988,7 +1002,15 @@ __global__ __launch_bounds__(128 * WGM, WGM == 2 ? 2 : 1) void k_gemm_bf_s(const
             C[(size_t)m * ldc + n] = v;
           }
         }
-      }
+    }
+  };
+  const bool full = m0 + BM <= M;  // workgroup-uniform
+  if (Chi) {
+    if (full) store_tile(std::false_type{}, std::true_type{});
+    else store_tile(std::true_type{}, std::true_type{});
+  } else {
+    if (full) store_tile(std::false_type{}, std::false_type{});
+    else store_tile(std::true_type{}, std::false_type{});
   }
 }
 

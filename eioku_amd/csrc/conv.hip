@@ -291,7 +291,13 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1(ConvArgs a, long long npix
     }
   }
   __syncthreads();
-  for (; g < groups; g += gstride) {
+  // FAST (r3): the plain layer - SiLU, fp16 output, no residual, whole cout tile inside Cout - on groups whose 32 pixels all
+  // exist runs a straight-line epilogue.  store_frag's run-time branches (and `p < npix`) hid from the compiler how many
+  // stores follow the next group's prefetch, so the first use of that prefetch waited with vmcnt(0): for the loads AND for
+  // the 2 NF stores just issued, a store round trip per group in kernels that run one wave per SIMD.
+  auto run = [&](auto fast_tag, long long gend) {
+  constexpr bool FAST = decltype(fast_tag)::value;
+  for (; g < gend; g += gstride) {
     float4v acc[2][NF];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -309,8 +315,12 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1(ConvArgs a, long long npix
         for (int j = 0; j < KB; ++j)
           if ((kb * KB + j) * 32 + u * 8 >= a.Cin) b[j][0] = b[j][1] = u32x4{0, 0, 0, 0};
       }
-      if (kb + 1 < nkb) load_blk(g, kb + 1, bn);
-      else if (g + gstride < groups) load_blk(g + gstride, 0, bn);  // next group's first block in flight
+      {
+        // ONE unconditional call (the group past the end re-reads the last pixels: load_blk clamps): with the loads in
+        // two branches the compiler could not count them and the block's first use waited with vmcnt(0)
+        const bool more = kb + 1 < nkb;
+        load_blk(more ? g : g + gstride, more ? kb + 1 : 0, bn);  // this group's next block / the next group's first
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < KB; ++j) {
@@ -331,7 +341,18 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1(ConvArgs a, long long npix
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (a.clsmax) {
+    if (FAST) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const size_t p = (size_t)(g * 32 + m * 16 + r);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const float4v v = silu4(acc[m][f] + float4v{biasr[f].x, biasr[f].y, biasr[f].z, biasr[f].w});
+          const f16x4 h = __builtin_convertvector(v, f16x4);  // RNE, as store_frag
+          STG(u32x2, a.out + p * a.out_cs + co_tile * ROWS + f * 16 + u * 4, __builtin_bit_cast(u32x2, h), a.x_out);
+        }
+      }
+    } else if (a.clsmax) {
       // lane (r, u) holds classes f*16 + u*4 + j of pixel r: ascending class order inside the lane (strict > keeps
       // the first maximum), then the 4 lanes of the pixel combine (ties: lower class), exactly k_decode's rule
 #pragma unroll
@@ -373,6 +394,10 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1(ConvArgs a, long long npix
       }
     }
   }
+  };
+  const bool fast = !a.clsmax && !a.out_f32 && !a.res && a.act == kActSiLU && (co_tile + 1) * ROWS <= a.Cout && (a.Cout & 3) == 0;
+  if (fast) run(std::true_type{}, npix / 32);  // the groups whose pixels all exist; a ragged last group runs below
+  run(std::false_type{}, groups);
 }
 
 // ---------------------------------------------------------------------------------------------
