@@ -404,13 +404,23 @@ __global__ __launch_bounds__(256) void k_box_gather(DecArgs a) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[m][f] = float4v{0.f, 0.f, 0.f, 0.f};
   const uint4* wl = a.bwgt[lvl] + r * 4 + u;  // packed [kc][64 rows][4 units], unswizzled in global memory
-  for (int kc = 0; kc < a.bnchunks; ++kc) {
+  // bias and every chunk's input fragments are requested up front (r3): per chunk and per store they were dependent round
+  // trips - and with a load pending, each epilogue store waited for the one before it (vmcnt completes in order)
+  float4 biasr[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) biasr[f] = *reinterpret_cast<const float4*>(a.bbias[lvl] + f * 16 + u * 4);
+  constexpr int kMaxKc = 4;
+  uint4 bfv[kMaxKc][2];
+#pragma unroll
+  for (int kc = 0; kc < kMaxKc; ++kc)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) bfv[kc][m] = *reinterpret_cast<const uint4*>(row[m] + (kc < a.bnchunks ? kc : 0) * 32);
+#pragma unroll
+  for (int kc = 0; kc < kMaxKc; ++kc) {
+    if (kc >= a.bnchunks) break;
     half8 bf[2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const uint4 v = *reinterpret_cast<const uint4*>(row[m] + kc * 32);
-      bf[m] = *reinterpret_cast<const half8*>(&v);
-    }
+    for (int m = 0; m < 2; ++m) bf[m] = *reinterpret_cast<const half8*>(&bfv[kc][m]);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const uint4 w = wl[(kc * 64 + f * 16) * 4];
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(256) void k_box_gather(DecArgs a) {
     float* o = a.box_w[lvl] + (img + loc[m]) * 64;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      const float4 b = *reinterpret_cast<const float4*>(a.bbias[lvl] + f * 16 + u * 4);
+      const float4 b = biasr[f];
       *reinterpret_cast<float4v*>(o + f * 16 + u * 4) = acc[m][f] + float4v{b.x, b.y, b.z, b.w};
     }
   }
@@ -664,6 +674,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_gather(GArgs ga) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int HW = g.H * g.W;
+  // the four bias vectors once, before the loop (r3): loaded inside the epilogue each store waited for its own bias load
+  // and, vmcnt being in order, for the store before it - eight round trips per pixel group
+  float4 biasr[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) biasr[f] = *reinterpret_cast<const float4*>(g.bias + f * 16 + q * 4);
   for (int g0 = (blockIdx.x * 4 + wave) * 32; g0 < cnt; g0 += gridDim.x * 4 * 32) {
     int gp[2], py[2], px[2];
     const __half* base[2];
@@ -733,7 +748,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_gather(GArgs ga) {
       if (g0 + m * 16 + r >= cnt) continue;
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const float4 b = *reinterpret_cast<const float4*>(g.bias + f * 16 + q * 4);
+        const float4 b = biasr[f];
         float4v v = acc[m][f] + float4v{b.x, b.y, b.z, b.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[j]));  // conv.hip's silu_f32
@@ -767,6 +782,7 @@ int decode_lazy_forward(float* const box[3], const unsigned long long* const cls
   }
   EIOKU_REQUIRE(A == max_cand, "candidate capacity %d != anchors %d", max_cand, A);
   a.bin_cs = lb.in_cs;
+  EIOKU_REQUIRE(lb.nchunks >= 1 && lb.nchunks <= 4, "box branch input of %d channels: k_box_gather stages at most 128", lb.nchunks * 32);
   a.bnchunks = lb.nchunks;
   a.N = N;
   a.nc = nc;
