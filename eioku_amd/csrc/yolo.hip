@@ -495,7 +495,7 @@ int run_ops(eioku_yolo* y, int n, int h, int w, hipStream_t stream, const FusedI
                          p2->in_buf == op.out_buf && p1->out_buf == op.out_buf && p2->out_buf == op.out_buf &&
                          p1->in_off == op.out_off && p2->in_off == p1->out_off && p1->out_off - p1->in_off == step &&
                          p2->out_off - p2->in_off == step && p1->in_ch == op.in_ch && p2->in_ch == op.in_ch &&
-                         op.in_buf == op.out_buf && (size_t)H * W * 32 <= 128 * 1024;
+                         op.in_buf == op.out_buf && (size_t)H * W * 48 <= 144 * 1024;
       if (pool_skip > 0) {
         --pool_skip;
         continue;

@@ -78,21 +78,36 @@ __global__ __launch_bounds__(256) void k_sppf_pools(const __half* in, int in_cs,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_pool[];
   half8* a = reinterpret_cast<half8*>(smem_pool);
   half8* b = a + H * W;
+  half8* t = b + H * W;  // row maxima of the current stage
   const int u = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, npx = H * W;
   const size_t base = (size_t)n * npx;
   for (int p = tid; p < npx; p += 256) a[p] = *reinterpret_cast<const half8*>(in + (base + p) * in_cs + u * 8);
   __syncthreads();
-  const _Float16 ninf = -__builtin_inff16();
+  // a 5 x 5 maximum is the column maximum of the row maxima: 5 + 5 LDS reads per pixel instead of 25, and with the
+  // window clamped into the map (a repeated element does not change a maximum) both passes are branch-free and unrolled
+  // (r3: the nested run-time loops of the 2-D window made this 30 us launch the longest non-conv step of the backbone)
   for (int stage = 0; stage < 3; ++stage) {
     const half8* src = (stage & 1) ? b : a;
     half8* dst = (stage & 1) ? a : b;
     for (int p = tid; p < npx; p += 256) {
       const int y = p / W, x = p - y * W;
-      half8 m = {ninf, ninf, ninf, ninf, ninf, ninf, ninf, ninf};
-      const int y0 = y - 2 < 0 ? 0 : y - 2, y1 = y + 2 >= H ? H - 1 : y + 2;
-      const int x0 = x - 2 < 0 ? 0 : x - 2, x1 = x + 2 >= W ? W - 1 : x + 2;
-      for (int yy = y0; yy <= y1; ++yy)
-        for (int xx = x0; xx <= x1; ++xx) m = __builtin_elementwise_max(m, src[yy * W + xx]);
+      half8 m = src[p];
+#pragma unroll
+      for (int d = 1; d <= 2; ++d) {
+        m = __builtin_elementwise_max(m, src[y * W + (x - d < 0 ? 0 : x - d)]);
+        m = __builtin_elementwise_max(m, src[y * W + (x + d >= W ? W - 1 : x + d)]);
+      }
+      t[p] = m;
+    }
+    __syncthreads();
+    for (int p = tid; p < npx; p += 256) {
+      const int y = p / W, x = p - y * W;
+      half8 m = t[p];
+#pragma unroll
+      for (int d = 1; d <= 2; ++d) {
+        m = __builtin_elementwise_max(m, t[(y - d < 0 ? 0 : y - d) * W + x]);
+        m = __builtin_elementwise_max(m, t[(y + d >= H ? H - 1 : y + d) * W + x]);
+      }
       if (stage < 2) dst[p] = m;
       *reinterpret_cast<half8*>(out + (base + p) * out_cs + stage * out_step + u * 8) = m;
     }
@@ -609,9 +624,9 @@ int letterbox_forward(const uint8_t* bgr, int n, const LetterboxPlan& p, __half*
 int sppf_pools_forward(Slice in, Slice out, int out_step, int N, int H, int W, int C, hipStream_t stream) {
   EIOKU_REQUIRE(C % 8 == 0 && in.cstride % 8 == 0 && in.coff % 8 == 0 && out.cstride % 8 == 0 && out.coff % 8 == 0 &&
                     out_step % 8 == 0, "maxpool slices must be 8-channel aligned");
-  EIOKU_REQUIRE((size_t)H * W * 32 <= 128 * 1024, "plane %dx%d too large for the fused SPPF pools", H, W);
+  EIOKU_REQUIRE((size_t)H * W * 48 <= 144 * 1024, "plane %dx%d too large for the fused SPPF pools", H, W);
   if (N == 0) return EIOKU_OK;
-  const size_t lds = (size_t)H * W * 32;
+  const size_t lds = (size_t)H * W * 48;  // two ping-pong planes + the row maxima, 16 B per pixel each
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
     EIOKU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sppf_pools), hipFuncAttributeMaxDynamicSharedMemorySize,
