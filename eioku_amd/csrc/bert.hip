@@ -838,6 +838,59 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
   lo[i] = l;
 }
 
+// Epilogue of the split-bf16 GEMMs.  The bias values are loaded first and waited for ONCE; the store loops are
+// branch-free on full tiles (rows past M exist only in the last row block) and the fp32 / planes choice is made outside
+// them.  With `if (m < M)` and `if (Chi)` around every store the compiler could not count the stores in flight behind the
+// bias load and put an s_waitcnt vmcnt(0) in front of every value: 64 store round trips per lane, one after the other -
+// the longest phase of the FFN1 GEMM (r3 ISA reading; profiles/r03_gemm_ablation.txt "neither": 255 us).
+template <int EPI, int WMT, int WNT, int BM>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[WMT][WNT], const float* __restrict__ bias, float* __restrict__ C,
+                                              unsigned short* __restrict__ Chi, unsigned short* __restrict__ Clo, int ldc,
+                                              int M, int m0, int n0, int wm, int wn, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  float bvs[WNT];
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) bvs[j] = bias ? bias[n0 + (wn * WNT + j) * 32 + l31] : 0.f;
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  __builtin_amdgcn_sched_barrier(0);
+  auto store_tile = [&](auto guard_tag, auto planes_tag) {
+    constexpr bool GUARD = decltype(guard_tag)::value, PLANES = decltype(planes_tag)::value;
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int n = n0 + (wn * WNT + j) * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * WMT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (GUARD && m >= M) continue;
+          float v = acc[i][j][r] + bvs[j];
+          if (EPI == 1) v = gelu_erf(v);
+          if (PLANES) {
+            // lanes n, n + 1 trade one term (quad_perm [1,0,3,2]): the even lane stores the pair of hi terms, the odd
+            // lane the pair of lo terms - one 4-byte store per lane, 128 contiguous bytes per 32 lanes, as on the fp32 side
+            unsigned short h, l;
+            split_bf16_one(v, h, l);
+            const bool odd = lane & 1;
+            const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h : l), 0xB1, 0xF, 0xF, true);
+            const unsigned word = odd ? (got | ((unsigned)l << 16)) : ((unsigned)h | (got << 16));
+            *reinterpret_cast<unsigned*>((odd ? Clo : Chi) + (size_t)m * ldc + (n & ~1)) = word;
+          } else {
+            C[(size_t)m * ldc + n] = v;
+          }
+        }
+    }
+  };
+  const bool full = m0 + BM <= M;  // workgroup-uniform
+  if (Chi) {
+    if (full) store_tile(std::false_type{}, std::true_type{});
+    else store_tile(std::true_type{}, std::true_type{});
+  } else {
+    if (full) store_tile(std::false_type{}, std::false_type{});
+    else store_tile(std::true_type{}, std::false_type{});
+  }
+}
+
 // WMT x WNT: 32x32 MFMA tiles per wave (the workgroup's tile is 64 WMT x 64 WNT).  1 x 1 for the small-M ingest path
 // (more workgroups); 2 x 2 for M >= 8192: 8 LDS fragment reads per 12 MFMAs instead of 16.  Stages are 64 deep.
 //
@@ -864,6 +917,10 @@ __global__ __launch_bounds__(128 * WGM, WGM == 2 ? 2 : 1) void k_gemm_bf_s(const
                                                       const unsigned short* __restrict__ Ahi,
                                                       const unsigned short* __restrict__ Alo,
                                                       unsigned short* __restrict__ Chi, unsigned short* __restrict__ Clo) {
+  // (r3, measured and removed: a double-buffered variant with 32-deep stages, two register sets two stages ahead and one
+  // barrier per stage - LDS stores of stage s + 1 beside the MFMAs of stage s, all waits counted - was bit-identical and
+  // SLOWER, 7.71 vs 7.35 ms per 512 x 128 batch: its 64-byte row segments double the L2 requests of loads that are
+  // L2-bandwidth bound already.)
   // WGM x 2 waves: the row block is 32 WMT WGM rows.  WGM = 4 (8 waves, 256 x 128 tiles, a quarter less L2 -> LDS traffic per
   // MFMA, one workgroup per CU) measured level with 2 (223 vs 227 us per GEMM: profiles/r03_gemm_ablation.txt) and is not
   // dispatched
@@ -966,52 +1023,7 @@ __global__ __launch_bounds__(128 * WGM, WGM == 2 ? 2 : 1) void k_gemm_bf_s(const
     }
     __syncthreads();
   }
-  // Epilogue.  The bias values are loaded first and waited for ONCE; the store loops below are branch-free on full
-  // tiles (rows past M exist only in the last row block) and the fp32 / planes choice is made outside them.  With
-  // `if (m < M)` and `if (Chi)` around every store the compiler could not count the stores in flight behind the bias
-  // load and put an s_waitcnt vmcnt(0) in front of every value: 64 store round trips per lane, one after the other -
-  // the longest phase of the FFN1 GEMM (r3 ISA reading; profiles/r03_gemm_ablation.txt "neither": 255 us).
-  float bvs[WNT];
-#pragma unroll
-  for (int j = 0; j < WNT; ++j) bvs[j] = bias ? bias[n0 + (wn * WNT + j) * 32 + l31] : 0.f;
-  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-  __builtin_amdgcn_sched_barrier(0);
-  auto store_tile = [&](auto guard_tag, auto planes_tag) {
-    constexpr bool GUARD = decltype(guard_tag)::value, PLANES = decltype(planes_tag)::value;
-#pragma unroll
-    for (int j = 0; j < WNT; ++j) {
-      const int n = n0 + (wn * WNT + j) * 32 + l31;
-#pragma unroll
-      for (int i = 0; i < WMT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * WMT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (GUARD && m >= M) continue;
-          float v = acc[i][j][r] + bvs[j];
-          if (EPI == 1) v = gelu_erf(v);
-          if (PLANES) {
-            // lanes n, n + 1 trade one term (quad_perm [1,0,3,2]): the even lane stores the pair of hi terms, the odd
-            // lane the pair of lo terms - one 4-byte store per lane, 128 contiguous bytes per 32 lanes, as on the fp32 side
-            unsigned short h, l;
-            split_bf16_one(v, h, l);
-            const bool odd = lane & 1;
-            const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h : l), 0xB1, 0xF, 0xF, true);
-            const unsigned word = odd ? (got | ((unsigned)l << 16)) : ((unsigned)h | (got << 16));
-            *reinterpret_cast<unsigned*>((odd ? Clo : Chi) + (size_t)m * ldc + (n & ~1)) = word;
-          } else {
-            C[(size_t)m * ldc + n] = v;
-          }
-        }
-    }
-  };
-  const bool full = m0 + BM <= M;  // workgroup-uniform
-  if (Chi) {
-    if (full) store_tile(std::false_type{}, std::true_type{});
-    else store_tile(std::true_type{}, std::true_type{});
-  } else {
-    if (full) store_tile(std::false_type{}, std::false_type{});
-    else store_tile(std::true_type{}, std::false_type{});
-  }
+  gemm_epilogue<EPI, WMT, WNT, BM>(acc, bias, C, Chi, Clo, ldc, M, m0, n0, wm, wn, lane);
 }
 
 constexpr int kMaxSplit = 4;
