@@ -166,7 +166,9 @@ __device__ __forceinline__ float4v activate_frag(const ConvArgs& a, const float4
   return v;
 }
 
-__device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc, size_t opix, int c0, float4 b,
+// `opix`: output pixel index; element offsets are 32-bit (the host entry points refuse tensors of 2^31 elements): one
+// v_mul_lo_u32 per address where size_t arithmetic cost a 64-bit multiply-add pair - per store, in every epilogue
+__device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc, unsigned opix, int c0, float4 b,
                                            bool have_rpre = false, u32x2 rpre = u32x2{0, 0}) {
   // native vector types throughout: arrays of the HIP uint2/uint4/__half structs end up in scratch memory
   if (c0 >= a.Cout) return;
@@ -178,7 +180,7 @@ __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc
   }
   const bool full = c0 + 3 < a.Cout;
   if (a.out_f32) {
-    float* o = a.out_f32 + opix * a.Cout + c0;
+    float* o = a.out_f32 + (size_t)(opix * (unsigned)a.Cout + (unsigned)c0);
     if (full && (a.Cout & 3) == 0) {
       STG(float4v, o, v, a.x_out);
     } else {
@@ -191,23 +193,23 @@ __device__ __forceinline__ void store_frag(const ConvArgs& a, const float4v& acc
   f16x4 h = __builtin_convertvector(v, f16x4);  // RNE
   if (full) {
     if (a.res) {
-      const u32x2 r = have_rpre ? rpre : LDG(u32x2, a.res + opix * a.res_cs + c0, a.x_res);
+      const u32x2 r = have_rpre ? rpre : LDG(u32x2, a.res + (size_t)(opix * (unsigned)a.res_cs + (unsigned)c0), a.x_res);
       float4v sum = __builtin_convertvector(h, float4v) + __builtin_convertvector(__builtin_bit_cast(f16x4, r), float4v);
       if (a.act == kActResReLU) sum = __builtin_elementwise_max(sum, float4v{0.f, 0.f, 0.f, 0.f});
       h = __builtin_convertvector(sum, f16x4);
     }
-    STG(u32x2, a.out + opix * a.out_cs + c0, __builtin_bit_cast(u32x2, h), a.x_out);
+    STG(u32x2, a.out + (size_t)(opix * (unsigned)a.out_cs + (unsigned)c0), __builtin_bit_cast(u32x2, h), a.x_out);
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (c0 + j < a.Cout) {
         _Float16 o = h[j];
         if (a.res) {
-          float sj = (float)o + (float)LDG(_Float16, a.res + opix * a.res_cs + c0 + j, a.x_res);
+          float sj = (float)o + (float)LDG(_Float16, a.res + (size_t)(opix * (unsigned)a.res_cs + (unsigned)(c0 + j)), a.x_res);
           if (a.act == kActResReLU) sj = fmaxf(sj, 0.f);
           o = (_Float16)sj;
         }
-        STG(_Float16, reinterpret_cast<_Float16*>(a.out) + opix * a.out_cs + c0 + j, o, a.x_out);
+        STG(_Float16, reinterpret_cast<_Float16*>(a.out) + (size_t)(opix * (unsigned)a.out_cs + (unsigned)(c0 + j)), o, a.x_out);
       }
   }
 }
@@ -344,12 +346,12 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1(ConvArgs a, long long npix
     if (FAST) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const size_t p = (size_t)(g * 32 + m * 16 + r);
+        const unsigned p = (unsigned)(g * 32 + m * 16 + r);
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           const float4v v = silu4(acc[m][f] + float4v{biasr[f].x, biasr[f].y, biasr[f].z, biasr[f].w});
           const f16x4 h = __builtin_convertvector(v, f16x4);  // RNE, as store_frag
-          STG(u32x2, a.out + p * a.out_cs + co_tile * ROWS + f * 16 + u * 4, __builtin_bit_cast(u32x2, h), a.x_out);
+          STG(u32x2, a.out + (size_t)(p * (unsigned)a.out_cs + (unsigned)(co_tile * ROWS + f * 16 + u * 4)), __builtin_bit_cast(u32x2, h), a.x_out);
         }
       }
     } else if (a.clsmax) {
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv1x1(ConvArgs a, long long npix
         const long long p = g * 32 + m * 16 + r;
         if (p >= npix) continue;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) store_frag(a, acc[m][f], (size_t)p, co_tile * ROWS + f * 16 + u * 4, biasr[f]);
+        for (int f = 0; f < NF; ++f) store_frag(a, acc[m][f], (unsigned)p, co_tile * ROWS + f * 16 + u * 4, biasr[f]);
       }
     }
   }
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   for (int m = 0; m < 2; ++m) {
     const int oh = oh0 + wave * 2 + m;
     if (oh >= a.Ho || ow >= a.Wo) continue;
-    const size_t opix = ((size_t)n * a.Ho + oh) * a.Wo + ow;
+    const unsigned opix = (unsigned)((n * a.Ho + oh) * a.Wo + ow);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int c0 = co_tile * 16 * NF + f * 16 + (lane >> 4) * 4;
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_flat(ConvArgs a, int npix, i
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int c0 = co_tile * 16 * NF + f * 16 + (lane >> 4) * 4;
-      store_frag(a, acc[m][f], (size_t)P, c0, *reinterpret_cast<const float4*>(a.bias + c0));
+      store_frag(a, acc[m][f], (unsigned)P, c0, *reinterpret_cast<const float4*>(a.bias + c0));
     }
   }
 }
@@ -842,11 +844,11 @@ __global__ __launch_bounds__(64 * NWV) void k_conv3x3_persist(ConvArgs a, int to
       for (int m = 0; m < 2; ++m) {
         const int oh = tth * kTH + wave * 2 + m;
         const bool ok = oh < a.Ho && ow < a.Wo;
-        const size_t opix = ((size_t)tn * a.Ho + (ok ? oh : 0)) * a.Wo + (ok ? ow : 0);
+        const unsigned opix = (unsigned)((tn * a.Ho + (ok ? oh : 0)) * a.Wo + (ok ? ow : 0));
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           const int c0 = co_tile * 16 * NF + f * 16 + (lane >> 4) * 4;
-          resv[m][f] = LDG(u32x2, a.res + opix * a.res_cs + (c0 + 3 < a.Cout ? c0 : 0), a.x_res);
+          resv[m][f] = LDG(u32x2, a.res + (size_t)(opix * (unsigned)a.res_cs + (unsigned)(c0 + 3 < a.Cout ? c0 : 0)), a.x_res);
         }
       }
     }
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv3x3_persist(ConvArgs a, int to
       for (int m = 0; m < 2; ++m) {
         const int oh = tth * kTH + wave * 2 + m;
         if (oh >= a.Ho || ow >= a.Wo) continue;
-        const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+        const unsigned opix = (unsigned)((tn * a.Ho + oh) * a.Wo + ow);
 #pragma unroll
         for (int f = 0; f < NF; ++f) store_frag(a2, acc2[m][f], opix, f * 16 + (lane >> 4) * 4, biasr2[f]);
       }
@@ -921,7 +923,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv3x3_persist(ConvArgs a, int to
       for (int m = 0; m < 2; ++m) {
         const int oh = tth * kTH + wave * 2 + m;
         if (oh >= a.Ho || ow >= a.Wo) continue;
-        const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+        const unsigned opix = (unsigned)((tn * a.Ho + oh) * a.Wo + ow);
 #pragma unroll
         for (int f = 0; f < NF; ++f)
           store_frag(a, acc[m][f], opix, co_tile * 16 * NF + f * 16 + (lane >> 4) * 4, biasr[f], res_vec, resv[m][f]);
@@ -1162,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, 
         resv[f] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(xb + pos * 4 + (unit ^ ((pos >> 1) & 3))) + half * 8);
       }
       if (CAT == 0 && (oh >= a.Ho || ow >= a.Wo)) continue;
-      const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+      const unsigned opix = (unsigned)((tn * a.Ho + oh) * a.Wo + ow);
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         // Cout = 16*NF exactly: always the full-vector store of store_frag, same roundings
@@ -1179,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, 
           const int unit = f * 2 + (lane >> 5), half = (lane >> 4) & 1;
           *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(xb + pos * 4 + (unit ^ ((pos >> 1) & 3))) + half * 8) = __builtin_bit_cast(u32x2, h);
         } else {
-          STG(u32x2, a.post_out + opix * a.post_out_cs + f * 16 + (lane >> 4) * 4, __builtin_bit_cast(u32x2, h), a.x_out);
+          STG(u32x2, a.post_out + (size_t)(opix * (unsigned)a.post_out_cs + (unsigned)(f * 16 + (lane >> 4) * 4)), __builtin_bit_cast(u32x2, h), a.x_out);
         }
       }
     }
@@ -1216,13 +1218,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_chain(ConvArgs a, ChainCat cc, 
       for (int m = 0; m < 2; ++m) {
         const int oh = tth * kTH + wave * 2 + m;
         if (oh >= a.Ho || ow >= a.Wo) continue;
-        const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+        const unsigned opix = (unsigned)((tn * a.Ho + oh) * a.Wo + ow);
 #pragma unroll
         for (int f = 0; f < NF2; ++f) {
           float4v v = acc2[m][f] + float4v{bias2[f].x, bias2[f].y, bias2[f].z, bias2[f].w};
           if (cc.act == kActSiLU) v = silu4(v);
           const f16x4 h = __builtin_convertvector(v, f16x4);
-          STG(u32x2, cc.out + opix * cc.out_cs + f * 16 + (lane >> 4) * 4, __builtin_bit_cast(u32x2, h), cc.x_out);
+          STG(u32x2, cc.out + (size_t)(opix * (unsigned)cc.out_cs + (unsigned)(f * 16 + (lane >> 4) * 4)), __builtin_bit_cast(u32x2, h), cc.x_out);
         }
       }
     }
@@ -1374,8 +1376,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_pair_rs(ConvArgs a, int rows
         h = __builtin_convertvector(sum, f16x4);
       }
       if (oh < a.Ho && ow < a.Wo) {
-        const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
-        STG(u32x2, a.post_out + opix * a.post_out_cs + 16 * wave + ku * 4, __builtin_bit_cast(u32x2, h), a.x_out);
+        const unsigned opix = (unsigned)((tn * a.Ho + oh) * a.Wo + ow);
+        STG(u32x2, a.post_out + (size_t)(opix * (unsigned)a.post_out_cs + (unsigned)(16 * wave + ku * 4)), __builtin_bit_cast(u32x2, h), a.x_out);
       }
     }
   }
@@ -1599,7 +1601,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_c8(ConvArgs a, FusedSrc fs, int
     for (int m = 0; m < 2; ++m) {
       const int oh = tth * kTH + wave * 2 + m;
       if (oh >= a.Ho || ow >= a.Wo) continue;
-      const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+      const unsigned opix = (unsigned)((tn * a.Ho + oh) * a.Wo + ow);
 #pragma unroll
       for (int f = 0; f < NF; ++f) store_frag(a, acc[m][f], opix, co_tile * ROWS + f * 16 + (lane >> 4) * 4, biasr[f]);
     }
@@ -1908,7 +1910,7 @@ __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st
     for (int m = 0; m < 2; ++m) {
       const int oh = tth * kTH + wave * 2 + m;
       if (oh >= a.Ho || ow >= a.Wo) continue;
-      const size_t opix = ((size_t)tn * a.Ho + oh) * a.Wo + ow;
+      const unsigned opix = (unsigned)((tn * a.Ho + oh) * a.Wo + ow);
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         float4v v = acc2[m][f] + float4v{bias2[f].x, bias2[f].y, bias2[f].z, bias2[f].w};
@@ -1916,7 +1918,7 @@ __global__ __launch_bounds__(256) void k_conv_stem_chain(ConvArgs a, StemArgs st
           v = silu4(v);
         }
         const f16x4 h = __builtin_convertvector(v, f16x4);
-        STG(u32x2, a.post_out + opix * a.post_out_cs + f * 16 + q * 4, __builtin_bit_cast(u32x2, h), a.x_out);
+        STG(u32x2, a.post_out + (size_t)(opix * (unsigned)a.post_out_cs + (unsigned)(f * 16 + q * 4)), __builtin_bit_cast(u32x2, h), a.x_out);
       }
     }
   }
@@ -2382,7 +2384,10 @@ int conv_chain_forward(const ConvWeights& ca, const ConvWeights& cb, Slice in, i
                            cat_in.coff % 8 == 0 && cat_out.ptr && cat_out.cstride % 4 == 0 && cat_out.coff % 4 == 0),
                 "the closing 1x1 cannot join this launch");
   if (N == 0) return EIOKU_OK;
-  EIOKU_REQUIRE((long long)N * H * W * in.cstride < (1ll << 31), "tensor exceeds 32-bit element offsets -- split the batch");
+  EIOKU_REQUIRE((long long)N * H * W * in.cstride < (1ll << 31) &&
+                    (long long)N * H * W * (out.cstride > cat_out.cstride ? out.cstride : cat_out.cstride) < (1ll << 31) &&
+                    (long long)N * H * W * cat_in.cstride < (1ll << 31),
+                "tensor exceeds 32-bit element offsets -- split the batch");
   ConvArgs a{};
   a.xcd_tiles = xcd_tiles_on();
   a.in = in.ptr + in.coff;
@@ -2470,6 +2475,7 @@ int conv_stem_chain_forward(const ConvWeights& stem, const ConvWeights& c1, cons
   EIOKU_REQUIRE(stem.d_w && c1.d_w && post.d_w && conv_stem_chain_ok(stem, c1, post, f, W), "layers cannot run as the fused front end");
   EIOKU_REQUIRE(out.ptr && out.cstride % 4 == 0 && out.coff % 4 == 0, "bad output slice");
   if (N == 0) return EIOKU_OK;
+  EIOKU_REQUIRE((long long)N * (H / 4) * (W / 4) * out.cstride < (1ll << 31), "tensor exceeds 32-bit element offsets -- split the batch");
   ConvArgs a{};
   a.xcd_tiles = xcd_tiles_on();
   a.wgt = reinterpret_cast<const uint4*>(c1.d_w);
@@ -2545,7 +2551,8 @@ int conv_forward(const ConvWeights& cw, Slice in, int N, int H, int W, Slice out
   {
     const long long px_in = (long long)N * H * W, px_out = (long long)N * conv_out_dim(H, cw.ks, cw.stride) * conv_out_dim(W, cw.ks, cw.stride);
     const int ocs = out_f32 ? cw.cout : out.cstride;
-    EIOKU_REQUIRE(px_in * (in.cstride > 8 ? in.cstride : 8) < (1ll << 31) && px_out * (ocs > 1 ? ocs : 1) < (1ll << 31),
+    EIOKU_REQUIRE(px_in * (in.cstride > 8 ? in.cstride : 8) < (1ll << 31) && px_out * (ocs > 1 ? ocs : 1) < (1ll << 31) &&
+                      px_out * (res.cstride > 1 ? res.cstride : 1) < (1ll << 31),
                   "tensor of %lld pixels exceeds the kernels' 32-bit element offsets -- split the batch", px_in);
   }
   ConvArgs a;
