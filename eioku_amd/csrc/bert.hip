@@ -1313,7 +1313,10 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
   // every GEMM of a layer on the split-bf16 kernels (the default): each activation a GEMM reads is written by its
   // producer as bf16 hi | lo planes; ctx and the FFN's 4H-wide intermediate then exist only in that form
   const int sp_o = pick_splits(T, H, H), sp_f = pick_splits(T, H, m->ffn);
-  const bool planes = gemm_takes_planes(H, 1) && gemm_takes_planes(H, sp_o) && gemm_takes_planes(m->ffn, sp_f);
+  // EIOKU_GEMM_PLANES=0: activations stay fp32 and the GEMMs split them in their staging threads (the r2 route; same
+  // function of the same values, so the embeddings must be the same bytes: tests/test_bert_gpu.py)
+  static const bool planes_on = env_on("EIOKU_GEMM_PLANES");
+  const bool planes = planes_on && gemm_takes_planes(H, 1) && gemm_takes_planes(H, sp_o) && gemm_takes_planes(m->ffn, sp_f);
   if ((rc = grow(&m->x, &m->x_cap, (size_t)T * H * 4))) return rc;
   if ((rc = grow(&m->y, &m->y_cap, (size_t)kMaxSplit * T * H * 4))) return rc;
   if ((rc = grow(&m->qkv, &m->qkv_cap, (size_t)T * 3 * H * 4))) return rc;
