@@ -435,6 +435,162 @@ __global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict_
     *reinterpret_cast<f32x4*>(op + 8 * g + 4 * half) = f32x4{o[4 * g] * rl, o[4 * g + 1] * rl, o[4 * g + 2] * rl, o[4 * g + 3] * rl};
 }
 
+// r3: the same (segment, head) attention on split bf16 (v = hi + lo, three product terms, fp32 accumulate - the GEMMs'
+// scheme).  The fp32 matrix pipe (64 cycles per 32x32x2 step) made k_attention_mfma matrix-bound: 8192 MFMA cycles per
+// wave; here QK^T and PV are 24 + 24 v_mfma_f32_32x32x16_bf16 = 1536 cycles.  Same structure: scores transposed
+// (S^T = K Q^T), so a lane owns one query and the softmax is in-register plus one cross-lane exchange, and the
+// accumulator registers of a key tile are, eight at a time, the B operand of O^T = V^T P^T: registers 8g..8g+7 of the two
+// half-waves hold the 16 keys 16g..16g+15 of the tile, and V^T sits in LDS with its keys in exactly that order, so that a
+// lane's A operand is one 16-byte read.  LDS: Q / K rows of 64 B (4 slots, slot ^= (row >> 2) & 3), V^T rows of 256 B
+// (16 slots, slot ^= dim & 15): every ds_read_b128 lane group touches 16 different bank quads.
+__global__ __launch_bounds__(256) void k_attention_bf(const float* __restrict__ qkv, const uint8_t* __restrict__ mask, int S,
+                                                      int H, float* __restrict__ ctx, unsigned short* __restrict__ chi,
+                                                      unsigned short* __restrict__ clo) {
+  constexpr int SP = 128;
+  __shared__ __attribute__((aligned(16))) u32x4b sQ[2][SP * 4];   // [plane][row][4 slots of 8 dims]
+  __shared__ __attribute__((aligned(16))) u32x4b sK[2][SP * 4];
+  __shared__ __attribute__((aligned(16))) unsigned short sVt[2][32 * SP];  // [plane][dim][128 permuted keys]
+  __shared__ float sM[SP];
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row0 = (size_t)b * S;
+  // staging: thread -> (row i >> 3, 4-dim group i & 7), 4 passes of 256 threads cover 128 rows x 8 groups
+  for (int i0 = 0; i0 < SP * 8; i0 += 4 * 256) {
+    f32x4 qq[4], kk[4], vv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = i0 + t * 256 + tid;
+      const int j = (i >> 3) < S ? (i >> 3) : S - 1;
+      const float* base = qkv + (row0 + j) * (size_t)(3 * H) + h * 32 + (i & 7) * 4;
+      qq[t] = *reinterpret_cast<const f32x4*>(base);
+      kk[t] = *reinterpret_cast<const f32x4*>(base + H);
+      vv[t] = *reinterpret_cast<const f32x4*>(base + 2 * H);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = i0 + t * 256 + tid;
+      const int j = i >> 3, u = i & 7;
+      const bool in = j < S;
+      unsigned qh0, ql0, qh1, ql1, kh0, kl0, kh1, kl1;
+      split_bf16_pair(in ? qq[t][0] : 0.f, in ? qq[t][1] : 0.f, qh0, ql0);
+      split_bf16_pair(in ? qq[t][2] : 0.f, in ? qq[t][3] : 0.f, qh1, ql1);
+      split_bf16_pair(in ? kk[t][0] : 0.f, in ? kk[t][1] : 0.f, kh0, kl0);
+      split_bf16_pair(in ? kk[t][2] : 0.f, in ? kk[t][3] : 0.f, kh1, kl1);
+      // dims 4u..4u+3 = half (u & 1) of slot u >> 1 of row j
+      const int slot = (u >> 1) ^ ((j >> 2) & 3), off = (j * 4 + slot) * 16 + (u & 1) * 8;
+      *reinterpret_cast<u32x2b*>(reinterpret_cast<unsigned char*>(sQ[0]) + off) = u32x2b{qh0, qh1};
+      *reinterpret_cast<u32x2b*>(reinterpret_cast<unsigned char*>(sQ[1]) + off) = u32x2b{ql0, ql1};
+      *reinterpret_cast<u32x2b*>(reinterpret_cast<unsigned char*>(sK[0]) + off) = u32x2b{kh0, kh1};
+      *reinterpret_cast<u32x2b*>(reinterpret_cast<unsigned char*>(sK[1]) + off) = u32x2b{kl0, kl1};
+      // V^T: key j -> position kt*32 + g*16 + half*8 + i8 with x = j & 15 = (i8 & 3) + 8 (i8 >> 2) + 4 half
+      const int x = j & 15, pos = (j & ~15) + ((x >> 2) & 1) * 8 + (x & 3) + 4 * (x >> 3);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d = u * 4 + e;
+        unsigned short vh, vl;
+        split_bf16_one(in ? vv[t][e] : 0.f, vh, vl);
+        const int p = d * SP + (((pos >> 3) ^ (d & 15)) << 3) + (pos & 7);
+        sVt[0][p] = vh;
+        sVt[1][p] = vl;
+      }
+    }
+  }
+  for (int j = tid; j < SP; j += 256) sM[j] = (j < S && mask[row0 + j]) ? 1.f : 0.f;
+  __syncthreads();
+  const int c = lane & 31, half = lane >> 5, q0 = wave * 32;
+  if (q0 >= S) return;  // a whole wave of padding queries (no barrier below)
+  // this wave's queries as B operands: 2 k-steps x (hi, lo)
+  bf16x8 bqh[2], bql[2];
+  {
+    const int qr = q0 + c;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int slot = (st * 2 + half) ^ ((qr >> 2) & 3);
+      bqh[st] = __builtin_bit_cast(bf16x8, sQ[0][qr * 4 + slot]);
+      bql[st] = __builtin_bit_cast(bf16x8, sQ[1][qr * 4 + slot]);
+    }
+  }
+  f32x16 sc[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+    const int kr = kt * 32 + c;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int slot = (st * 2 + half) ^ ((kr >> 2) & 3);
+      const bf16x8 akh = __builtin_bit_cast(bf16x8, sK[0][kr * 4 + slot]);
+      const bf16x8 akl = __builtin_bit_cast(bf16x8, sK[1][kr * 4 + slot]);
+      sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(akh, bqh[st], sc[kt], 0, 0, 0);
+      sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(akl, bqh[st], sc[kt], 0, 0, 0);
+      sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(akh, bql[st], sc[kt], 0, 0, 0);
+    }
+  }
+  // sc[kt][r] = <k_key, q_query>, key = kt*32 + (r & 3) + 8*(r >> 2) + 4*half, query = q0 + c
+  const float rinv = 0.17677669529663687f;  // 1 / sqrt(32)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float s = sM[key] != 0.f ? sc[kt][r] * rinv : -INFINITY;
+      sc[kt][r] = s;
+      mx = fmaxf(mx, s);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float l = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = sc[kt][r] != -INFINITY ? expf(sc[kt][r] - mx) : 0.f;
+      sc[kt][r] = e;
+      l += e;
+    }
+  l += __shfl_xor(l, 32, 64);
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      // P^T operand: this lane's 8 probabilities of key block (kt, g), split into their two bf16 terms
+      unsigned ph[4], pl[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_bf16_pair(sc[kt][8 * g + 2 * e], sc[kt][8 * g + 2 * e + 1], ph[e], pl[e]);
+      const bf16x8 bph = __builtin_bit_cast(bf16x8, u32x4b{ph[0], ph[1], ph[2], ph[3]});
+      const bf16x8 bpl = __builtin_bit_cast(bf16x8, u32x4b{pl[0], pl[1], pl[2], pl[3]});
+      // V^T operand: dim c, keys of the same block and half, one 16-byte unit
+      const int unit = ((kt * 4 + g * 2 + half) ^ (c & 15));
+      const bf16x8 avh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(&sVt[0][c * SP + unit * 8]));
+      const bf16x8 avl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(&sVt[1][c * SP + unit * 8]));
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avh, bph, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl, bph, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avh, bpl, o, 0, 0, 0);
+    }
+  // o[r] = O[query][dim], dim = (r & 3) + 8*(r >> 2) + 4*half
+  const int qi = q0 + c;
+  if (qi >= S) return;
+  const float rl = l > 0.f ? 1.0f / l : 0.f;  // fully masked segment -> zeros (its pooled vector is 0 anyway)
+  const size_t o0 = (row0 + qi) * (size_t)H + h * 32;
+  if (chi) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      unsigned h0, l0, h1, l1;
+      split_bf16_pair(o[4 * g] * rl, o[4 * g + 1] * rl, h0, l0);
+      split_bf16_pair(o[4 * g + 2] * rl, o[4 * g + 3] * rl, h1, l1);
+      *reinterpret_cast<u32x2b*>(chi + o0 + 8 * g + 4 * half) = u32x2b{h0, h1};
+      *reinterpret_cast<u32x2b*>(clo + o0 + 8 * g + 4 * half) = u32x2b{l0, l1};
+    }
+    return;
+  }
+  float* op = ctx + o0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<f32x4*>(op + 8 * g + 4 * half) = f32x4{o[4 * g] * rl, o[4 * g + 1] * rl, o[4 * g + 2] * rl, o[4 * g + 3] * rl};
+}
+
 // S <= 256: 8 lanes per query (keys j = lane, lane + 8, ...), 32 queries per workgroup.  Each lane keeps its <= 32
 // scores in registers (the old kernel computed every score twice: once for the max, once for the exponent) and
 // the K / V rows are swizzled by row so that the 8 rows a query group reads at once hit 8 different bank groups.
@@ -1361,7 +1517,10 @@ int eioku_bert_embed(eioku_bert* m, const int32_t* ids, const uint8_t* mask, int
     const std::string p = "encoder.layer." + std::to_string(l) + ".";
     if ((rc = gemm(m->x, H, tp(m, p + "attention.self.query.weight"), tp(m, p + "attention.self.query.bias"), m->qkv,
                    3 * H, T, 3 * H, H, 0, 1, stream, &m->wsplit[(size_t)4 * l + 0], xa))) return rc;
-    if (amfma) {
+    static const bool abf = env_on("EIOKU_ATTN_BF16");  // 0: the exact-fp32 matrix pipe (k_attention_mfma)
+    if (amfma && abf) {
+      hipLaunchKernelGGL(k_attention_bf, dim3(B, m->heads), dim3(256), 0, stream, m->qkv, d_mask, S, H, m->ctx, cP.hi, cP.lo);
+    } else if (amfma) {
       hipLaunchKernelGGL(k_attention_mfma, dim3(B, m->heads), dim3(256), 0, stream, m->qkv, d_mask, S, H, m->ctx, cP.hi, cP.lo);
     } else {
       if (parts == 4)

@@ -140,7 +140,8 @@ def test_fp32_fma_route_matches_the_mfma_route(gpu, tmp_path):
     want = np.load(GOLDEN / "minilm_seed11.npz")["out"]
     outs = {}
     for name, env in {"mfma": {}, "fma": {"EIOKU_GEMM_BF16": "0", "EIOKU_GEMM_S": "0", "EIOKU_ATTN_MFMA": "0"},
-                      "fma_s": {"EIOKU_GEMM_BF16": "0"}, "no_planes": {"EIOKU_GEMM_PLANES": "0"}}.items():
+                      "fma_s": {"EIOKU_GEMM_BF16": "0"}, "no_planes": {"EIOKU_GEMM_PLANES": "0"},
+                      "attn_f32": {"EIOKU_ATTN_BF16": "0"}}.items():
         path = tmp_path / f"{name}.npy"
         subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=dict(os.environ, **env), timeout=300)
         outs[name] = np.load(path)
@@ -150,3 +151,5 @@ def test_fp32_fma_route_matches_the_mfma_route(gpu, tmp_path):
     # r3: activations as bf16 planes written by their producers vs fp32 activations split inside the GEMM's staging
     # threads - the same split of the same values, so the same bytes
     assert np.array_equal(outs["no_planes"], outs["mfma"])
+    # r3: attention on split bf16 (default) vs on the exact-fp32 matrix pipe
+    assert np.abs(outs["attn_f32"] - outs["mfma"]).max() <= 2e-5
