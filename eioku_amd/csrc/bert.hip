@@ -1,16 +1,22 @@
 // K8: all-MiniLM-L6-v2 style BERT encoder + masked mean pooling + L2 normalisation (gfx950).
 //
 // The reference holds intent only for this stage (.kiro/specs/semantic-video-search/design.md:54-57,
-// 1096-1103); BASELINE.json asks for embeddings within 1e-4 relative of the fp32 CPU path, so every
-// matmul runs on the exact-fp32 matrix core (v_mfma_f32_32x32x2_f32; there is no TF32-like mode on
-// gfx950) with LayerNorm / softmax / GELU(erf) in fp32.
+// 1096-1103); BASELINE.json asks for embeddings within 1e-4 relative of the fp32 CPU path.  gfx950 has no TF32-like
+// mode and its exact-fp32 matrix pipe is 157 TFLOP/s, so the default route splits every operand into two bf16 terms
+// (v = hi + lo to 2^-18, round to nearest) and runs a.w ~ a_hi.w_hi + a_lo.w_hi + a_hi.w_lo on the bf16 matrix cores with
+// fp32 accumulation; LayerNorm / softmax / GELU(erf) are fp32.  Embeddings land at 7-10 % of the 1e-4 bar against the
+// float64 oracle (tools/embed_margin.py).  The exact-fp32 kernels stay reachable for the cross-check test
+// (EIOKU_GEMM_BF16=0, EIOKU_GEMM_S=0, EIOKU_ATTN_MFMA=0, EIOKU_ATTN_BF16=0).
 //
-//   k_embed_ln     word + position + token_type(0) embedding gather, LayerNorm        (HBM-bound)
-//   k_gemm_f32     C = A . W^T + bias [, GELU]   128x128x32 tiles, 4 waves x (2x2) 32x32 MFMA tiles,
-//                  register-staged double-buffered LDS, XOR-swizzled for ds_read_b128    (MFMA-bound)
-//   k_attention    per (segment, head): two-pass softmax(QK^T/sqrt(dh) + mask) V, K/V in LDS
-//   k_add_ln       LayerNorm(x + residual)
-//   k_pool_norm    attention-mask weighted mean over tokens, then x / max(|x|, 1e-12)
+//   k_embed_ln        word + position + token_type(0) embedding gather, LayerNorm -> fp32 x + bf16 hi / lo planes
+//   k_gemm_bf_s       C = A . W^T + bias [, GELU] on split bf16: A and W arrive as planes, 128x128 (M >= 8192) or
+//                     64x64 tiles, 64-deep register-staged stages, XCD-aware tile order, straight-line epilogue that
+//                     writes fp32 or planes
+//   k_attention_bf    per (segment, head), S <= 128: S^T = K Q^T and O^T = V^T P^T on split bf16, softmax in registers
+//   k_attention_mfma / k_attention8 / k_attention   the exact-fp32 and longer-sequence variants
+//   k_add_ln_fixed    LayerNorm(sum of split-K planes + bias + residual) -> fp32 x + planes
+//   k_pool_norm       attention-mask weighted mean over tokens, then x / max(|x|, 1e-12)
+//   k_gemm_f32*       exact-fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32): the fallback route
 #include "common.h"
 
 #include <cstdlib>
