@@ -182,30 +182,24 @@ __global__ __launch_bounds__(256) void k_add_ln(const float* __restrict__ a, int
 // ---------------------------------------------------------------------------------------------
 constexpr int kBK = 32;
 
-// erf to <= 1.7 ulp (checked against 40-digit values on 60 k points of [-6, 6] and a normal sample in fp32 arithmetic:
-// tools/fit_erf.py, which also derived the minimax coefficients).  |a| <= 0.9277: a + a p(a^2); beyond: 1 - exp(t q(t) - t),
-// t clamped to 4 (erf = 1 in fp32 from 3.92).  Both sides are evaluated and selected - lanes of a wave differ anyway -
-// in ~22 instructions; the library erff costs ~40, and the GELU epilogue of the FFN1 GEMM (100 M values per 512-segment
-// batch) was its longest phase: 255 of 498 us with loads and MFMAs ablated away (profiles/r03_gemm_ablation.txt).
+// erf for the GELU epilogue: 1 - exp(t q(t) - t) with t = min(|a|, 4) (erf = 1 in fp32 from 3.92) and q a degree-8
+// minimax polynomial of (log erfc(t) + t) / t on [0, 4] (tools/fit_erf.py fits it and checks it: GELU(x) within 4.4e-7
+// ABSOLUTE of 40-digit values on [-8, 8], i.e. within one fp32 ulp of |x| >= 4 and far inside the path's 1e-4 bar;
+// near 0 the RELATIVE error of erf is not ulp-level - 1 - exp(small) - but GELU multiplies it by x / 2).  One
+// branch-free form in 14 instructions; the library erff costs ~40, a two-branch 1.7-ulp polynomial 22, and the GELU
+// epilogue of the FFN1 GEMM runs 100 M of them per 512-segment batch.
 __device__ __forceinline__ float erf_poly(float a) {
-  const float t = fabsf(a), s = a * a;
-  float r = -5.987081095e-04f;
-  r = fmaf(r, s, 4.992952105e-03f);
-  r = fmaf(r, s, -2.676688507e-02f);
-  r = fmaf(r, s, 1.128183827e-01f);
-  r = fmaf(r, s, -3.761249781e-01f);
-  r = fmaf(r, s, 1.283791512e-01f);
-  const float small = fmaf(r, a, a);
-  const float tc = fminf(t, 4.0f);
-  float q = -1.620942385e-05f;
-  q = fmaf(q, tc, 3.676992783e-04f);
-  q = fmaf(q, tc, -3.796639154e-03f);
-  q = fmaf(q, tc, 2.400766313e-02f);
-  q = fmaf(q, tc, -1.064029485e-01f);
-  q = fmaf(q, tc, -6.351379156e-01f);
-  q = fmaf(q, tc, -1.286272407e-01f);
-  const float big = copysignf(1.0f - __expf(fmaf(q, tc, -tc)), a);
-  return t > 0.927734375f ? big : small;
+  const float t = fminf(fabsf(a), 4.0f);
+  float q = 2.050339617e-06f;
+  q = fmaf(q, t, -3.688787547e-05f);
+  q = fmaf(q, t, 2.615261183e-04f);
+  q = fmaf(q, t, -7.679130649e-04f);
+  q = fmaf(q, t, -1.059674076e-03f);
+  q = fmaf(q, t, 2.006150223e-02f);
+  q = fmaf(q, t, -1.031126305e-01f);
+  q = fmaf(q, t, -6.365721822e-01f);
+  q = fmaf(q, t, -1.283802688e-01f);
+  return copysignf(1.0f - __expf(fmaf(q, t, -t)), a);
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_poly(x * 0.70710678118654752440f)); }
